@@ -1,0 +1,47 @@
+"""pytest configuration: `gpu` marker + shared helpers for loading golden fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def load_cfg(kind):
+    raw = np.load(os.path.join(GOLDEN, f"micro_{kind}_config.npz"))
+    cfg = {}
+    for k, v in raw.items():
+        v = v.item() if v.ndim == 0 else v
+        cfg[k] = str(v) if isinstance(v, (str, np.str_)) else v
+    return cfg
+
+
+def load_weights(kind):
+    return dict(np.load(os.path.join(GOLDEN, f"micro_{kind}_weights.npz")))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def unpack_masks(z, key):
+    shape = tuple(int(x) for x in z[key.replace("masks", "shape")])
+    return np.unpackbits(z[key])[: int(np.prod(shape))].reshape(shape)
+
+
+def chain_or_none(z):
+    return z["chain"] if z["chain"].size else None
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
