@@ -1,0 +1,887 @@
+// hd_api.hip -- host side of libhudiff_hip.so: the C ABI declared in include/hudiff_hip.h.
+//
+// Replaces, for the sampling path only, the reference's
+//   model_selected + load_state_dict   (utils/train_utils.py:43-55, antibody_scripts/sample.py:456-458)
+//   AntiTFNet.forward / NanoAntiTFNet.forward   (model/encoder/model.py:366-384, model/nanoencoder/model.py:325-343)
+//   the T-step loop                    (antibody_scripts/sample.py:499-513, nanobody_scripts/nanosample.py:316-329)
+// There is no CPU fallback: without a gfx950 device every entry point fails with HD_ERR_NO_DEVICE.
+#include "../../include/hudiff_hip.h"
+#include "hd_kernels.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace hd;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static HdStatus fail(HdStatus st, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(HD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define HD_TRY(expr)                                                                               \
+    do {                                                                                           \
+        HdStatus s_ = (expr);                                                                      \
+        if (s_ != HD_OK) return s_;                                                                \
+    } while (0)
+
+extern "C" const char* hd_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ByteNetW {   // one ByteNet block, both segments packed back to back
+    const float *ln1_g, *ln1_b, *w1, *b1, *ln2_g, *ln2_b, *wc, *bc, *ln3_g, *ln3_b, *w3, *b3;
+    int dil;
+};
+struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; };
+struct AttBlockW {
+    AttLayerW a1, a2;
+    const float *n1_g, *n1_b, *n2_g, *n2_b, *wf1, *bf1, *wf2, *bf2;
+};
+
+struct Workspace {
+    int capB = 0;
+    float *X = nullptr, *H1 = nullptr, *H2 = nullptr;        // token encoder: [M,d], [M,dh] x2
+    float *FEAT = nullptr, *Y = nullptr, *G1 = nullptr, *G2 = nullptr;  // conv stage: [M,D] x2, [M,Dh] x2
+    float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
+    float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
+    float2* ST = nullptr;
+    float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
+    int32_t *tokens = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
+    int capT = 0;
+    float* qnoise = nullptr; size_t qnoise_cap = 0;
+    uint8_t *enc_masks = nullptr, *conv_masks = nullptr; size_t enc_cap = 0, conv_cap = 0;
+    std::vector<void*> owned;
+};
+
+struct HdModel {
+    HdConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;
+    // derived
+    int nseg = 1, d = 0, dh = 0, D = 0, Dh = 0, A = 0, Fd = 0, L = 0;
+    float p_enc = 0.f, p_conv = 0.f;
+    // device weights
+    float* blob = nullptr;
+    const float* emb = nullptr;
+    std::vector<ByteNetW> enc, conv;
+    std::vector<AttBlockW> att;
+    RegionW regw{};
+    SideW sidew{};
+    const float *pos_w1 = nullptr, *pos_b1 = nullptr, *pos_w2 = nullptr, *pos_b2 = nullptr;
+    HeadW head{};
+    const float *rope_cos = nullptr, *rope_sin = nullptr;
+    float* side_vec = nullptr;
+    RunState* rs = nullptr;
+    Workspace ws;
+    // sampling session
+    bool in_session = false;
+    int sB = 0, sTmax = 0;
+    uint32_t sflags = 0;
+    bool s_has_q = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_B = -1; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_steps = 0; bool timed = false;
+};
+
+static int dilation_of(const HdConfig& c, int n) {
+    int log2r = 0;
+    while ((1 << (log2r + 1)) <= c.r) ++log2r;
+    return 1 << (n % (log2r + 1));
+}
+
+extern "C" int hd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" double hd_flops_per_row_forward(const HdConfig* c) {
+    const double L = c->max_len, d = c->d_model, dh = c->d_model / 2, D = c->sum_d_model, Dh = c->sum_d_model / 2;
+    const double A = c->att_model, Fd = c->dim_feedforward, k = c->kernel_size;
+    return L * (c->n_encoder_layers * (4 * d * dh + 2 * k * dh * dh) + c->dual_layers * (4 * D * Dh + 2 * k * Dh * Dh) +
+                2.0 * c->cs_layers * (8 * D * A + 4 * L * A) + c->cs_layers * 4 * D * Fd + 2 * D * c->n_tokens);
+}
+
+extern "C" HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
+    if (!cfg || !out) return fail(HD_ERR_INVALID, "hd_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != HD_ABI_VERSION)
+        return fail(HD_ERR_INVALID, "hd_create: abi_version %d != %d", cfg->abi_version, HD_ABI_VERSION);
+    int ndev = hd_device_count();
+    if (ndev <= 0) return fail(HD_ERR_NO_DEVICE, "hd_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(HD_ERR_INVALID, "hd_create: device %d out of range [0,%d)", device, ndev);
+    const HdConfig& c = *cfg;
+    if (c.kind != HD_KIND_ANTIBODY && c.kind != HD_KIND_NANOBODY) return fail(HD_ERR_INVALID, "hd_create: kind %d", c.kind);
+    if (c.att_model != c.nhead * ATT_HD)
+        return fail(HD_ERR_UNSUPPORTED, "hd_create: head dim %d/%d unsupported (kernels implement 64)", c.att_model, c.nhead);
+    const int nkt = (c.max_len + 15) / 16;
+    if (nkt != 19 && nkt != 10)
+        return fail(HD_ERR_UNSUPPORTED, "hd_create: max_len %d unsupported (291 or 152)", c.max_len);
+    if (c.d_model % 8 || c.sum_d_model % 8 || c.dim_feedforward % 4 || c.d_model > 512 || c.sum_d_model > 1024)
+        return fail(HD_ERR_UNSUPPORTED, "hd_create: widths must be multiples of 8 (d_model<=512, sum_d_model<=1024)");
+    if (c.r_embedding > 8 || c.s_embedding > 8 || c.n_tokens < 23 || c.n_tokens > 64)
+        return fail(HD_ERR_UNSUPPORTED, "hd_create: r_embedding/s_embedding <= 8, n_tokens in [23,64]");
+    if (c.kind == HD_KIND_ANTIBODY) {
+        if (c.h_len <= 0 || c.h_len >= c.max_len) return fail(HD_ERR_INVALID, "hd_create: h_len %d", c.h_len);
+        if (c.sum_d_model != 3 * c.d_model) return fail(HD_ERR_INVALID, "hd_create: sum_d_model != 3*d_model");
+    } else {
+        if (c.h_len != c.max_len) return fail(HD_ERR_INVALID, "hd_create: nanobody h_len must equal max_len");
+        if (c.sum_d_model != 2 * c.d_model) return fail(HD_ERR_INVALID, "hd_create: sum_d_model != 2*d_model");
+    }
+    if (c.kernel_size != 7 && c.kernel_size != 5 && c.kernel_size != 3)
+        return fail(HD_ERR_UNSUPPORTED, "hd_create: kernel_size %d", c.kernel_size);
+    if (!(c.dropout >= 0.f && c.dropout < 1.f)) return fail(HD_ERR_INVALID, "hd_create: dropout %f", c.dropout);
+    for (int a : {c.enc_act, c.conv_act})
+        if (a != HD_ACT_RELU && a != HD_ACT_GELU) return fail(HD_ERR_INVALID, "hd_create: activation %d", a);
+
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HD_ERR_NO_DEVICE, "hd_create: device %d is %s, kernels are built for gfx950 only", device, prop.gcnArchName);
+    HdModel* m = new HdModel();
+    m->cfg = c;
+    m->device = device;
+    m->nseg = c.kind == HD_KIND_ANTIBODY ? 2 : 1;
+    m->d = c.d_model; m->dh = c.d_model / 2; m->D = c.sum_d_model; m->Dh = c.sum_d_model / 2;
+    m->A = c.att_model; m->Fd = c.dim_feedforward; m->L = c.max_len;
+    m->p_enc = c.dropout;
+    m->p_conv = c.dropout > 0.f ? 0.5f : 0.f;   // F.dropout(x) default p, gated by cfg.dropout > 0 (model.py:295-303)
+    hipError_t e = hipStreamCreate(&m->stream);
+    if (e != hipSuccess) { delete m; return fail(HD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    hipEventCreate(&m->ev0);
+    hipEventCreate(&m->ev1);
+    *out = m;
+    return HD_OK;
+}
+
+static void free_ws(Workspace& ws) {
+    for (void* p : ws.owned) hipFree(p);
+    ws = Workspace();
+}
+
+extern "C" void hd_destroy(HdModel* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) hipGraphDestroy(m->graph);
+    free_ws(m->ws);
+    if (m->blob) hipFree(m->blob);
+    if (m->side_vec) hipFree(m->side_vec);
+    if (m->rs) hipFree(m->rs);
+    if (m->ev0) hipEventDestroy(m->ev0);
+    if (m->ev1) hipEventDestroy(m->ev1);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+extern "C" HdStatus hd_load_tensor(HdModel* m, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!m || !key || !shape || ndim < 0 || ndim > 4) return fail(HD_ERR_INVALID, "hd_load_tensor: bad argument");
+    if (m->finalized) return fail(HD_ERR_STATE, "hd_load_tensor: model already finalized");
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);          // antibody_train.py:23-30 strips this prefix
+    if (ends_with(k, ".rope") || k == "pos_encoder.pos_embedding.pe") return HD_OK;   // recomputable buffers
+    if (!data) return fail(HD_ERR_INVALID, "hd_load_tensor: null data for %s", key);
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(HD_ERR_INVALID, "hd_load_tensor: %s bad shape", key); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    m->host[k] = std::move(t);
+    return HD_OK;
+}
+
+// ---- weight packing ---------------------------------------------------------------------------
+struct Packer {
+    std::vector<float> buf;
+    size_t add(const std::vector<float>& v) {
+        size_t off = (buf.size() + 63) / 64 * 64;
+        buf.resize(off);
+        buf.insert(buf.end(), v.begin(), v.end());
+        return off;
+    }
+};
+
+struct Loader {
+    HdModel* m;
+    std::map<std::string, bool> used;
+    std::string err;
+    const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+        auto it = m->host.find(key);
+        if (it == m->host.end()) { if (err.empty()) err = "missing tensor '" + key + "'"; return nullptr; }
+        std::vector<int64_t> want(shape);
+        if (it->second.shape != want) {
+            if (err.empty()) {
+                err = "tensor '" + key + "' has shape [";
+                for (auto s : it->second.shape) err += std::to_string(s) + ",";
+                err += "] expected [";
+                for (auto s : want) err += std::to_string(s) + ",";
+                err += "]";
+            }
+            return nullptr;
+        }
+        used[key] = true;
+        return &it->second;
+    }
+    // vector [n]
+    std::vector<float> vec(const std::string& key, int64_t n) {
+        auto t = get(key, {n});
+        return t ? t->data : std::vector<float>((size_t)n, 0.f);
+    }
+    // torch Linear weight [out, in] -> [in, out]
+    std::vector<float> lin_t(const std::string& key, int64_t out, int64_t in, bool conv1 = false) {
+        const HostTensor* t = conv1 ? get(key, {out, in, 1}) : get(key, {out, in});
+        std::vector<float> r((size_t)(in * out), 0.f);
+        if (t) for (int64_t o = 0; o < out; ++o) for (int64_t i = 0; i < in; ++i) r[(size_t)(i * out + o)] = t->data[(size_t)(o * in + i)];
+        return r;
+    }
+    // Conv1d weight [out, in, k] -> [k][in][out]
+    std::vector<float> conv_t(const std::string& key, int64_t out, int64_t in, int64_t k) {
+        auto t = get(key, {out, in, k});
+        std::vector<float> r((size_t)(k * in * out), 0.f);
+        if (t) for (int64_t o = 0; o < out; ++o) for (int64_t i = 0; i < in; ++i) for (int64_t j = 0; j < k; ++j)
+            r[(size_t)((j * in + i) * out + o)] = t->data[(size_t)((o * in + i) * k + j)];
+        return r;
+    }
+};
+
+static void append(std::vector<float>& a, const std::vector<float>& b) { a.insert(a.end(), b.begin(), b.end()); }
+
+struct ByteNetOff { size_t ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3; };
+
+static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::string>& prefixes, int din, int dh, int ks) {
+    std::vector<float> ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3;
+    for (const auto& p : prefixes) {
+        append(ln1_g, ld.vec(p + "sequence1.0.weight", din)); append(ln1_b, ld.vec(p + "sequence1.0.bias", din));
+        append(w1, ld.lin_t(p + "sequence1.2.conv.weight", dh, din, true)); append(b1, ld.vec(p + "sequence1.2.conv.bias", dh));
+        append(ln2_g, ld.vec(p + "sequence1.3.weight", dh)); append(ln2_b, ld.vec(p + "sequence1.3.bias", dh));
+        append(wc, ld.conv_t(p + "conv.weight", dh, dh, ks)); append(bc, ld.vec(p + "conv.bias", dh));
+        append(ln3_g, ld.vec(p + "sequence2.0.weight", dh)); append(ln3_b, ld.vec(p + "sequence2.0.bias", dh));
+        append(w3, ld.lin_t(p + "sequence2.2.conv.weight", din, dh, true)); append(b3, ld.vec(p + "sequence2.2.conv.bias", din));
+    }
+    ByteNetOff o;
+    o.ln1_g = pk.add(ln1_g); o.ln1_b = pk.add(ln1_b); o.w1 = pk.add(w1); o.b1 = pk.add(b1);
+    o.ln2_g = pk.add(ln2_g); o.ln2_b = pk.add(ln2_b); o.wc = pk.add(wc); o.bc = pk.add(bc);
+    o.ln3_g = pk.add(ln3_g); o.ln3_b = pk.add(ln3_b); o.w3 = pk.add(w3); o.b3 = pk.add(b3);
+    return o;
+}
+
+struct AttLayerOff { size_t wqkv, bqkv, wo, bo; };
+static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, const std::string& p, int D, int A) {
+    // fused [D, 3A] = [query | key | value]
+    auto q = ld.lin_t(p + "query.weight", A, D), k = ld.lin_t(p + "key.weight", A, D), v = ld.lin_t(p + "value.weight", A, D);
+    std::vector<float> w((size_t)D * 3 * A);
+    for (int i = 0; i < D; ++i) {
+        memcpy(&w[(size_t)i * 3 * A], &q[(size_t)i * A], sizeof(float) * A);
+        memcpy(&w[(size_t)i * 3 * A + A], &k[(size_t)i * A], sizeof(float) * A);
+        memcpy(&w[(size_t)i * 3 * A + 2 * A], &v[(size_t)i * A], sizeof(float) * A);
+    }
+    std::vector<float> b;
+    append(b, ld.vec(p + "query.bias", A)); append(b, ld.vec(p + "key.bias", A)); append(b, ld.vec(p + "value.bias", A));
+    AttLayerOff o;
+    o.wqkv = pk.add(w); o.bqkv = pk.add(b);
+    o.wo = pk.add(ld.lin_t(p + "out_put.weight", D, A)); o.bo = pk.add(ld.vec(p + "out_put.bias", D));
+    return o;
+}
+
+extern "C" HdStatus hd_finalize(HdModel* m) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_finalize: null model");
+    if (m->finalized) return fail(HD_ERR_STATE, "hd_finalize: already finalized");
+    HIP_TRY(hipSetDevice(m->device));
+    const HdConfig& c = m->cfg;
+    const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, A = m->A, Fd = m->Fd, L = m->L, ks = c.kernel_size;
+    Loader ld{m};
+    Packer pk;
+    const bool ab = c.kind == HD_KIND_ANTIBODY;
+    const std::vector<std::string> segn = ab ? std::vector<std::string>{"h_layers", "l_layers"} : std::vector<std::string>{"layers"};
+    const std::string convp = ab ? "dual_conv_block." : "nano_conv_block.";
+
+    // embedder [n_tokens, d]
+    std::vector<float> embv;
+    { auto t = ld.get("aa_encoder.embedder.weight", {c.n_tokens, d}); embv = t ? t->data : std::vector<float>((size_t)c.n_tokens * d); }
+    const size_t o_emb = pk.add(embv);
+    std::vector<ByteNetOff> enc_off, conv_off;
+    for (int n = 0; n < c.n_encoder_layers; ++n) {
+        std::vector<std::string> pf;
+        for (auto& s : segn) pf.push_back("aa_encoder." + s + "." + std::to_string(n) + ".");
+        enc_off.push_back(pack_bytenet(ld, pk, pf, d, dh, ks));
+    }
+    for (int n = 0; n < c.dual_layers; ++n) {
+        std::vector<std::string> pf;
+        for (auto& s : segn) pf.push_back(convp + s + "." + std::to_string(n) + ".");
+        conv_off.push_back(pack_bytenet(ld, pk, pf, D, Dh, ks));
+    }
+    struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2; };
+    std::vector<AttOff> att_off;
+    for (int n = 0; n < c.cs_layers; ++n) {
+        std::string p = "self_at.layers." + std::to_string(n) + ".";
+        AttOff o;
+        o.a1 = pack_attlayer(ld, pk, p + "attn_hl.", D, A);
+        o.a2 = pack_attlayer(ld, pk, p + "attn_hl_c.", D, A);
+        o.n1_g = pk.add(ld.vec(p + "norm_hl1.weight", D)); o.n1_b = pk.add(ld.vec(p + "norm_hl1.bias", D));
+        o.n2_g = pk.add(ld.vec(p + "norm_hl2.weight", D)); o.n2_b = pk.add(ld.vec(p + "norm_hl2.bias", D));
+        o.wf1 = pk.add(ld.lin_t(p + "ff_hl.0.weight", Fd, D)); o.bf1 = pk.add(ld.vec(p + "ff_hl.0.bias", Fd));
+        o.wf2 = pk.add(ld.lin_t(p + "ff_hl.2.weight", D, Fd)); o.bf2 = pk.add(ld.vec(p + "ff_hl.2.bias", D));
+        att_off.push_back(o);
+    }
+    // region / position branch
+    const int re = c.r_embedding;
+    size_t r_emb, r_l0g, r_l0b, r_w, r_b, r_l1g, r_l1b, r_pe;
+    { auto t = ld.get("region_encoder.region_embedding.weight", {c.n_region, re}); r_emb = pk.add(t ? t->data : std::vector<float>((size_t)c.n_region * re)); }
+    r_l0g = pk.add(ld.vec("region_encoder.region_layer1.0.weight", re)); r_l0b = pk.add(ld.vec("region_encoder.region_layer1.0.bias", re));
+    r_w = pk.add(ld.lin_t("region_encoder.region_layer1.2.conv.weight", d, re, true)); r_b = pk.add(ld.vec("region_encoder.region_layer1.2.conv.bias", d));
+    r_l1g = pk.add(ld.vec("region_encoder.region_layer1.3.weight", d)); r_l1b = pk.add(ld.vec("region_encoder.region_layer1.3.bias", d));
+    {   // sinusoid table, float32 arithmetic as torch builds the 'pe' buffer (model/encoder/model.py:70-78)
+        std::vector<float> pe((size_t)L * d);
+        for (int i = 0; i < d; i += 2) {
+            float div = expf((float)i * (float)(-log(10000.0) / d));
+            for (int l = 0; l < L; ++l) {
+                float ang = (float)l * div;
+                pe[(size_t)l * d + i] = sinf(ang);
+                pe[(size_t)l * d + i + 1] = cosf(ang);
+            }
+        }
+        r_pe = pk.add(pe);
+    }
+    size_t p_w1 = pk.add(ld.lin_t("pos_encoder.pos_lin.ln1.weight", 2 * d, d)), p_b1 = pk.add(ld.vec("pos_encoder.pos_lin.ln1.bias", 2 * d));
+    size_t p_w2 = pk.add(ld.lin_t("pos_encoder.pos_lin.ln2.weight", d, 2 * d)), p_b2 = pk.add(ld.vec("pos_encoder.pos_lin.ln2.bias", d));
+    size_t s_emb = 0, s_w1 = 0, s_b1 = 0, s_lg = 0, s_lb = 0, s_w2 = 0, s_b2 = 0;
+    const int se = c.s_embedding;
+    if (ab) {
+        { auto t = ld.get("side_encoder.side_embeddinng.weight", {c.n_side, se}); s_emb = pk.add(t ? t->data : std::vector<float>((size_t)c.n_side * se)); }
+        s_w1 = pk.add(ld.lin_t("side_encoder.side_mlp.0.weight", d, se)); s_b1 = pk.add(ld.vec("side_encoder.side_mlp.0.bias", d));
+        s_lg = pk.add(ld.vec("side_encoder.side_mlp.1.weight", d)); s_lb = pk.add(ld.vec("side_encoder.side_mlp.1.bias", d));
+        s_w2 = pk.add(ld.lin_t("side_encoder.side_mlp.3.weight", d, d)); s_b2 = pk.add(ld.vec("side_encoder.side_mlp.3.bias", d));
+    }
+    size_t h_g = pk.add(ld.vec("last_norm.weight", D)), h_b = pk.add(ld.vec("last_norm.bias", D));
+    size_t h_w, h_bias;
+    { auto t = ld.get("decoder.weight", {c.n_tokens, D}); h_w = pk.add(t ? t->data : std::vector<float>((size_t)c.n_tokens * D)); }
+    h_bias = pk.add(ld.vec("decoder.bias", c.n_tokens));
+    // RoPE table (cross_attention.py:35-56): angle = t * theta^(-2k/hd), float32 like torch
+    size_t o_cos, o_sin;
+    {
+        std::vector<float> cs((size_t)L * 32), sn((size_t)L * 32);
+        for (int k = 0; k < 32; ++k) {
+            float freq = 1.0f / powf(10000.0f, (float)(2 * k) / (float)ATT_HD);
+            for (int t = 0; t < L; ++t) {
+                float ang = (float)t * freq;
+                cs[(size_t)t * 32 + k] = cosf(ang);
+                sn[(size_t)t * 32 + k] = sinf(ang);
+            }
+        }
+        o_cos = pk.add(cs); o_sin = pk.add(sn);
+    }
+    if (!ld.err.empty()) return fail(HD_ERR_STATE, "hd_finalize: %s", ld.err.c_str());
+    for (auto& kv : m->host)
+        if (!ld.used.count(kv.first)) return fail(HD_ERR_INVALID, "hd_finalize: unexpected tensor '%s' (strict load)", kv.first.c_str());
+
+    HIP_TRY(hipMalloc(&m->blob, pk.buf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->blob, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* B0 = m->blob;
+    m->emb = B0 + o_emb;
+    auto mk = [&](const ByteNetOff& o, int n) {
+        ByteNetW w{B0 + o.ln1_g, B0 + o.ln1_b, B0 + o.w1, B0 + o.b1, B0 + o.ln2_g, B0 + o.ln2_b, B0 + o.wc, B0 + o.bc,
+                   B0 + o.ln3_g, B0 + o.ln3_b, B0 + o.w3, B0 + o.b3, dilation_of(c, n)};
+        return w;
+    };
+    for (int n = 0; n < c.n_encoder_layers; ++n) m->enc.push_back(mk(enc_off[n], n));
+    for (int n = 0; n < c.dual_layers; ++n) m->conv.push_back(mk(conv_off[n], n));
+    for (auto& o : att_off) {
+        AttBlockW w;
+        w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo};
+        w.a2 = {B0 + o.a2.wqkv, B0 + o.a2.bqkv, B0 + o.a2.wo, B0 + o.a2.bo};
+        w.n1_g = B0 + o.n1_g; w.n1_b = B0 + o.n1_b; w.n2_g = B0 + o.n2_g; w.n2_b = B0 + o.n2_b;
+        w.wf1 = B0 + o.wf1; w.bf1 = B0 + o.bf1; w.wf2 = B0 + o.wf2; w.bf2 = B0 + o.bf2;
+        m->att.push_back(w);
+    }
+    m->regw = {B0 + r_emb, B0 + r_l0g, B0 + r_l0b, B0 + r_w, B0 + r_b, B0 + r_l1g, B0 + r_l1b, B0 + r_pe};
+    m->pos_w1 = B0 + p_w1; m->pos_b1 = B0 + p_b1; m->pos_w2 = B0 + p_w2; m->pos_b2 = B0 + p_b2;
+    if (ab) m->sidew = {B0 + s_emb, B0 + s_w1, B0 + s_b1, B0 + s_lg, B0 + s_lb, B0 + s_w2, B0 + s_b2};
+    m->head = {B0 + h_g, B0 + h_b, B0 + h_w, B0 + h_bias};
+    m->rope_cos = B0 + o_cos; m->rope_sin = B0 + o_sin;
+    HIP_TRY(hipMalloc(&m->rs, sizeof(RunState)));
+    HIP_TRY(hipMemset(m->rs, 0, sizeof(RunState)));
+    if (ab) {
+        HIP_TRY(hipMalloc(&m->side_vec, sizeof(float) * c.n_side * d));
+        hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, m->stream, m->sidew, se, d, m->side_vec);
+        HIP_TRY(hipGetLastError());
+    }
+    const size_t smem = (size_t)L * (ATT_KS + ATT_VS) * sizeof(float);
+    if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->host.clear();
+    m->finalized = true;
+    return HD_OK;
+}
+
+// ---- workspace ----------------------------------------------------------------------------------
+template <typename T>
+static HdStatus dalloc(Workspace& ws, T** p, size_t n) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(T) + 256));
+    ws.owned.push_back(q);
+    *p = (T*)q;
+    return HD_OK;
+}
+
+static HdStatus ensure_ws(HdModel* m, int B) {
+    Workspace& ws = m->ws;
+    if (B <= ws.capB) return HD_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    m->graph_B = -1;
+    free_ws(ws);
+    const size_t M = (size_t)B * m->L;
+    const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, A = m->A, Fd = m->Fd;
+    HD_TRY(dalloc(ws, &ws.X, M * d)); HD_TRY(dalloc(ws, &ws.H1, M * dh)); HD_TRY(dalloc(ws, &ws.H2, M * dh));
+    HD_TRY(dalloc(ws, &ws.FEAT, M * D)); HD_TRY(dalloc(ws, &ws.Y, M * D));
+    HD_TRY(dalloc(ws, &ws.G1, M * Dh)); HD_TRY(dalloc(ws, &ws.G2, M * Dh));
+    HD_TRY(dalloc(ws, &ws.QKV, M * 3 * A)); HD_TRY(dalloc(ws, &ws.O, M * A)); HD_TRY(dalloc(ws, &ws.AT, M * D));
+    HD_TRY(dalloc(ws, &ws.F1, M * Fd));
+    HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
+    HD_TRY(dalloc(ws, &ws.ST, M));
+    HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
+    HD_TRY(dalloc(ws, &ws.tokens, M)); HD_TRY(dalloc(ws, &ws.region, M)); HD_TRY(dalloc(ws, &ws.chain, (size_t)2 * B));
+    HD_TRY(dalloc(ws, &ws.T, (size_t)B));
+    ws.capB = B;
+    return HD_OK;
+}
+
+static Segs make_segs(const HdModel* m, int B) {
+    Segs s{};
+    s.nseg = m->nseg; s.B = B; s.L = m->L;
+    s.len[0] = m->cfg.h_len; s.off[0] = 0; s.base[0] = 0;
+    s.len[1] = m->L - m->cfg.h_len; s.off[1] = m->cfg.h_len; s.base[1] = B * m->cfg.h_len;
+    return s;
+}
+
+// ---- kernel launch helpers ----------------------------------------------------------------------
+struct Drop { int mode = DROP_NONE; float p = 0.f; uint32_t site = 0; const uint8_t* mask = nullptr; };
+
+static GemmP base_gemm(const HdModel* m, const Segs& sg) {
+    GemmP p{};
+    p.sg = sg; p.taps = 1; p.dil = 1; p.rs = m->rs;
+    return p;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
+    Segs run = p.sg;
+    if (!per_seg) {           // weights shared by all rows: treat the whole batch as one segment
+        run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0;
+        // NB: with nseg = 1 rows are contiguous [0, B*L); slot bookkeeping is not needed by shared-weight GEMMs
+    }
+    GemmP q = p;
+    q.sg = run;
+    const int rows0 = run.B * run.len[0];
+    const int rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
+    q.tiles0 = (rows0 + BM - 1) / BM;
+    const int tiles = q.tiles0 + (rows1 + BM - 1) / BM;
+    dim3 grid(tiles, (q.N + BN - 1) / BN);
+    if (conv) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, q);
+}
+
+static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
+    const long rows = (long)p.sg.B * p.sg.L;
+    if (rows >= 8192) launch_gemm_t<128, 128, 2, 2>(p, conv, per_seg, st);
+    else launch_gemm_t<32, 128, 1, 4>(p, conv, per_seg, st);
+}
+
+static void launch_stats(const HdModel* m, const float* X, int ldx, int C, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(row_stats_k, dim3((rows + 3) / 4), dim3(256), 0, st, X, ldx, C, rows, m->ws.ST);
+}
+
+static void set_drop(GemmP& p, const Drop& dr) {
+    p.drop_mode = dr.mode;
+    if (dr.mode == DROP_NONE) return;
+    double t = floor((double)dr.p * 4294967296.0);
+    p.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    p.drop_scale = (float)(1.0 / (1.0 - (double)dr.p));
+    p.drop_site = dr.site;
+    p.drop_mask = dr.mask;
+}
+
+// One ByteNet block:  out = dropout(x + PFF2(act(LN(conv(act(LN(PFF1(act(LN(x))))))))))   [+ extra]
+static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
+                          const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
+                          const Drop& dr, const float* extra, int lde) {
+    hipStream_t st = m->stream;
+    const int rows = sg.rows();
+    const int ks = m->cfg.kernel_size;
+    launch_stats(m, x, ldx, din, rows, st);
+    GemmP p = base_gemm(m, sg);
+    p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
+    p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
+    p.stats = m->ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act;
+    launch_gemm(p, false, true, st);
+
+    launch_stats(m, h1, dh, dh, rows, st);
+    p = base_gemm(m, sg);
+    p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
+    p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
+    p.stats = m->ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act;
+    launch_gemm(p, true, true, st);
+
+    launch_stats(m, h2, dh, dh, rows, st);
+    p = base_gemm(m, sg);
+    p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
+    p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
+    p.stats = m->ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
+    set_drop(p, dr);
+    launch_gemm(p, false, true, st);
+}
+
+static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
+                            const float* g, const float* b, const float* resid, float* out) {
+    hipStream_t st = m->stream;
+    const int D = m->D, A = m->A;
+    GemmP p = base_gemm(m, sg);
+    p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = m->ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
+    if (ln) { p.stats = m->ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
+    launch_gemm(p, false, false, st);
+    const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
+    dim3 grid(sg.B * m->cfg.nhead);
+    if (m->L > 160)
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(256), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+    else
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(256), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+    p = base_gemm(m, sg);
+    p.A = m->ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
+    p.resid = resid; p.ldr = D;
+    launch_gemm(p, false, false, st);
+}
+
+// The token-independent branch (RegionEmbedder, PosEmbedder, SideEmbedder): once per batch.
+static HdStatus static_branch(HdModel* m, const Segs& sg) {
+    hipStream_t st = m->stream;
+    Workspace& ws = m->ws;
+    const int d = m->d, D = m->D, rows = sg.rows();
+    hipLaunchKernelGGL(region_embed_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.region, m->regw, m->cfg.r_embedding, d, ws.POS, sg);
+    // pos = x + W2 gelu(W1 x + b1) + b2      (MLP model.py:28-33; nn.Dropout is inactive in eval mode)
+    GemmP p = base_gemm(m, sg);
+    p.A = ws.POS; p.lda = d; p.W = m->pos_w1; p.bias = m->pos_b1; p.C = ws.PH; p.ldc = 2 * d; p.N = 2 * d; p.Kc = d; p.epi_act = ACT_GELU;
+    launch_gemm(p, false, false, st);
+    p = base_gemm(m, sg);
+    p.A = ws.PH; p.lda = 2 * d; p.W = m->pos_w2; p.bias = m->pos_b2; p.C = ws.POS; p.ldc = d; p.N = d; p.Kc = 2 * d;
+    p.resid = ws.POS; p.ldr = d;
+    launch_gemm(p, false, false, st);
+    hipLaunchKernelGGL(static_feature_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.POS,
+                       m->nseg > 1 ? m->side_vec : nullptr, ws.chain, d, D, ws.EXTRA, ws.FEAT, sg);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+// One denoiser forward up to the last attention block; result rows in ws.Y.
+static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks) {
+    hipStream_t st = m->stream;
+    Workspace& ws = m->ws;
+    const HdConfig& c = m->cfg;
+    const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
+    hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, d, ws.X, sg);
+    const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
+    for (int n = 0; n < c.n_encoder_layers; ++n) {
+        Drop dr;
+        if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
+        const bool last = n == c.n_encoder_layers - 1;
+        bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
+                      last ? ws.EXTRA : nullptr, d);
+    }
+    for (int n = 0; n < c.dual_layers; ++n) {
+        Drop dr;
+        if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
+        bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0);
+    }
+    for (int n = 0; n < c.cs_layers; ++n) {
+        const AttBlockW& w = m->att[n];
+        // at = x + A1(x)
+        attention_layer(m, sg, w.a1, ws.Y, false, nullptr, nullptr, ws.Y, ws.AT);
+        // at = at + A2(LN1(at))
+        launch_stats(m, ws.AT, D, D, rows, st);
+        attention_layer(m, sg, w.a2, ws.AT, true, w.n1_g, w.n1_b, ws.AT, ws.AT);
+        // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
+        launch_stats(m, ws.AT, D, D, rows, st);
+        GemmP p = base_gemm(m, sg);
+        p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
+        p.stats = ws.ST; p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;
+        launch_gemm(p, false, false, st);
+        p = base_gemm(m, sg);
+        p.A = ws.F1; p.lda = m->Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Y; p.ldc = D; p.N = D; p.Kc = m->Fd;
+        p.resid = ws.Y; p.ldr = D;
+        launch_gemm(p, false, false, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+static HdStatus validate_inputs(const HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain, int B) {
+    const int L = m->L;
+    for (long i = 0; i < (long)B * L; ++i) {
+        if (tokens[i] < 0 || tokens[i] >= m->cfg.n_tokens) return fail(HD_ERR_INVALID, "token %d at row %ld slot %ld out of [0,%d)", tokens[i], i / L, i % L, m->cfg.n_tokens);
+        if (region[i] < 0 || region[i] >= m->cfg.n_region) return fail(HD_ERR_INVALID, "region %d at row %ld slot %ld out of [0,%d)", region[i], i / L, i % L, m->cfg.n_region);
+    }
+    if (m->nseg > 1) {
+        if (!chain) return fail(HD_ERR_INVALID, "antibody model needs chain types [2B]");
+        for (int b = 0; b < B; ++b) {
+            if (chain[b] != 0) return fail(HD_ERR_INVALID, "chain[%d] = %d: heavy rows must be 0 (H)", b, chain[b]);
+            if (chain[B + b] < 1 || chain[B + b] >= m->cfg.n_side) return fail(HD_ERR_INVALID, "chain[%d] = %d: light rows must be in [1,%d)", B + b, chain[B + b], m->cfg.n_side);
+        }
+    }
+    return HD_OK;
+}
+
+static HdStatus upload_common(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain, int B) {
+    Workspace& ws = m->ws;
+    const size_t M = (size_t)B * m->L;
+    HIP_TRY(hipMemcpyAsync(ws.tokens, tokens, M * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(ws.region, region, M * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    if (m->nseg > 1) HIP_TRY(hipMemcpyAsync(ws.chain, chain, (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    return HD_OK;
+}
+
+static HdStatus set_run_state(HdModel* m, uint64_t seed, uint64_t row0, uint32_t step) {
+    RunState h{};
+    h.step = step; h.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu); h.seed_hi = (uint32_t)(seed >> 32); h.row0 = (uint32_t)row0;
+    HIP_TRY(hipMemcpyAsync(m->rs, &h, sizeof(h), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));   // h is a stack object
+    return HD_OK;
+}
+
+static int drop_mode_of(const HdModel* m, uint32_t flags) {
+    const uint32_t f = flags & HD_DROPOUT_MASK;
+    if (f == HD_DROPOUT_OFF || m->cfg.dropout <= 0.f) return DROP_NONE;
+    if (f == HD_DROPOUT_INJECT) return DROP_INJECT;
+    return DROP_GEN;
+}
+
+template <typename T>
+static HdStatus ensure_buf(HdModel* m, T** p, size_t* cap, size_t n) {
+    if (n <= *cap) return HD_OK;
+    HD_TRY(dalloc(m->ws, p, n));
+    *cap = n;
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                               int32_t B, uint32_t flags, uint64_t seed, uint64_t row0, uint32_t step,
+                               const uint8_t* enc_masks, const uint8_t* conv_masks, float* logits) {
+    if (!m || !tokens || !region || !logits) return fail(HD_ERR_INVALID, "hd_forward: null argument");
+    if (!m->finalized) return fail(HD_ERR_STATE, "hd_forward: call hd_finalize first");
+    if (m->in_session) return fail(HD_ERR_STATE, "hd_forward: a sampling session is open (hd_sample_end it first)");
+    if (B < 0) return fail(HD_ERR_INVALID, "hd_forward: B = %d", B);
+    if (B == 0) return HD_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HD_TRY(validate_inputs(m, tokens, region, chain, B));
+    const int dm = drop_mode_of(m, flags);
+    if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_forward: HD_DROPOUT_INJECT needs enc_masks and conv_masks");
+    HD_TRY(ensure_ws(m, B));
+    Workspace& ws = m->ws;
+    const Segs sg = make_segs(m, B);
+    HD_TRY(upload_common(m, tokens, region, chain, B));
+    HD_TRY(set_run_state(m, seed, row0, step));
+    const uint8_t *dem = nullptr, *dcm = nullptr;
+    if (dm == DROP_INJECT) {
+        const size_t ne = (size_t)m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)m->cfg.dual_layers * B * m->L * m->D;
+        HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
+        HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
+        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->stream));
+        dem = ws.enc_masks; dcm = ws.conv_masks;
+    }
+    HD_TRY(static_branch(m, sg));
+    HD_TRY(forward_body(m, sg, dm, dem, dcm));
+    const int rows = sg.rows();
+    hipLaunchKernelGGL(decode_all_k, dim3((rows + 3) / 4), dim3(256), 0, m->stream, ws.Y, m->D, m->head, m->cfg.n_tokens, ws.LOGITS, sg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return HD_OK;
+}
+
+// ---- sampling session ---------------------------------------------------------------------------
+static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, const uint8_t* cm) {
+    HD_TRY(forward_body(m, sg, dm, em, cm));
+    Workspace& ws = m->ws;
+    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, m->stream, ws.Y, m->D, m->head, ws.tokens, ws.order, ws.T,
+                       m->sTmax, m->s_has_q ? ws.qnoise : nullptr, m->rs, sg);
+    hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, m->stream, m->rs);
+    HIP_TRY(hipGetLastError());
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                                    const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                                    uint64_t seed, uint64_t row0, const float* q_noise,
+                                    const uint8_t* enc_masks, const uint8_t* conv_masks) {
+    if (!m || !tokens || !region || !T || (Tmax > 0 && !order)) return fail(HD_ERR_INVALID, "hd_sample_begin: null argument");
+    if (!m->finalized) return fail(HD_ERR_STATE, "hd_sample_begin: call hd_finalize first");
+    if (m->in_session) return fail(HD_ERR_STATE, "hd_sample_begin: session already open");
+    if (B < 0 || Tmax < 0) return fail(HD_ERR_INVALID, "hd_sample_begin: B = %d, Tmax = %d", B, Tmax);
+    HIP_TRY(hipSetDevice(m->device));
+    m->sB = B; m->sTmax = Tmax; m->sflags = flags; m->s_has_q = q_noise != nullptr; m->timed = false; m->last_steps = 0;
+    if (B == 0) { m->in_session = true; return HD_OK; }
+    HD_TRY(validate_inputs(m, tokens, region, chain, B));
+    for (int b = 0; b < B; ++b) {
+        if (T[b] < 0 || T[b] > Tmax) return fail(HD_ERR_INVALID, "T[%d] = %d out of [0,%d]", b, T[b], Tmax);
+        for (int t = 0; t < T[b]; ++t) {
+            int s = order[(size_t)b * Tmax + t];
+            if (s < 0 || s >= m->L) return fail(HD_ERR_INVALID, "order[%d,%d] = %d out of [0,%d)", b, t, s, m->L);
+        }
+    }
+    const int dm = drop_mode_of(m, flags);
+    if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_sample_begin: HD_DROPOUT_INJECT needs masks");
+    HD_TRY(ensure_ws(m, B));
+    Workspace& ws = m->ws;
+    const Segs sg = make_segs(m, B);
+    HD_TRY(upload_common(m, tokens, region, chain, B));
+    {
+        size_t cap = (size_t)ws.capT;
+        size_t need = (size_t)B * (Tmax > 0 ? Tmax : 1);
+        if (need > cap) { HD_TRY(dalloc(ws, &ws.order, need)); ws.capT = (int)need; }
+    }
+    if (Tmax > 0) HIP_TRY(hipMemcpyAsync(ws.order, order, (size_t)B * Tmax * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(ws.T, T, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    if (q_noise && Tmax > 0) {
+        const size_t n = (size_t)Tmax * B * 22;
+        HD_TRY(ensure_buf(m, &ws.qnoise, &ws.qnoise_cap, n));
+        HIP_TRY(hipMemcpyAsync(ws.qnoise, q_noise, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    }
+    if (dm == DROP_INJECT && Tmax > 0) {
+        const size_t ne = (size_t)Tmax * m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)Tmax * m->cfg.dual_layers * B * m->L * m->D;
+        HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
+        HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
+        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->stream));
+    }
+    HD_TRY(set_run_state(m, seed, row0, 0));
+    HD_TRY(static_branch(m, sg));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->in_session = true;
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
+    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_run: no open session");
+    if (t0 < 0 || t1 < t0 || t1 > m->sTmax) return fail(HD_ERR_INVALID, "hd_sample_run: steps [%d,%d) outside [0,%d]", t0, t1, m->sTmax);
+    if (m->sB == 0 || t1 == t0) return HD_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const Segs sg = make_segs(m, m->sB);
+    const int dm = drop_mode_of(m, m->sflags);
+    Workspace& ws = m->ws;
+    hipLaunchKernelGGL(set_step_k, dim3(1), dim3(1), 0, m->stream, m->rs, (uint32_t)t0);
+    const bool use_graph = !(m->sflags & HD_NO_GRAPH) && dm != DROP_INJECT;
+    if (use_graph) {
+        if (!m->graph_exec || m->graph_B != m->sB || m->graph_drop != dm || m->graph_q != m->s_has_q || m->graph_Tmax != m->sTmax) {
+            if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+            HdStatus s = one_step(m, sg, dm, nullptr, nullptr);
+            hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+            if (s != HD_OK) return s;
+            if (e != hipSuccess) return fail(HD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            m->graph_B = m->sB; m->graph_drop = dm; m->graph_q = m->s_has_q; m->graph_Tmax = m->sTmax;
+        }
+        HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        for (int t = t0; t < t1; ++t) HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+        HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    } else {
+        const size_t es = (size_t)m->cfg.n_encoder_layers * m->sB * m->L * m->d, cs = (size_t)m->cfg.dual_layers * m->sB * m->L * m->D;
+        HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        for (int t = t0; t < t1; ++t)
+            HD_TRY(one_step(m, sg, dm, dm == DROP_INJECT ? ws.enc_masks + (size_t)t * es : nullptr,
+                            dm == DROP_INJECT ? ws.conv_masks + (size_t)t * cs : nullptr));
+        HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    }
+    m->timed = true;
+    m->last_steps = t1 - t0;
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sync(HdModel* m) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_sync: null model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
+    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_end: no open session");
+    m->in_session = false;
+    if (m->sB == 0) return HD_OK;
+    if (!tokens) return fail(HD_ERR_INVALID, "hd_sample_end: null tokens");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(tokens, m->ws.tokens, (size_t)m->sB * m->L * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample(HdModel* m, int32_t* tokens, const int32_t* region, const int32_t* chain,
+                              const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                              uint64_t seed, uint64_t row0, const float* q_noise,
+                              const uint8_t* enc_masks, const uint8_t* conv_masks) {
+    HD_TRY(hd_sample_begin(m, tokens, region, chain, order, T, B, Tmax, flags, seed, row0, q_noise, enc_masks, conv_masks));
+    int tmax_eff = 0;
+    for (int b = 0; b < B; ++b) tmax_eff = T[b] > tmax_eff ? T[b] : tmax_eff;
+    HdStatus s = hd_sample_run(m, 0, tmax_eff);
+    if (s != HD_OK) { m->in_session = false; return s; }
+    return hd_sample_end(m, tokens);
+}
+
+extern "C" HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps) {
+    if (!m || !ms) return fail(HD_ERR_INVALID, "hd_last_run_ms: null argument");
+    if (!m->timed) return fail(HD_ERR_STATE, "hd_last_run_ms: no timed run");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventSynchronize(m->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
+    if (steps) *steps = m->last_steps;
+    return HD_OK;
+}

@@ -1,0 +1,677 @@
+// hd_kernels.hip.h -- device kernels of libhudiff_hip.so (gfx950 / CDNA4 only, wave = 64).
+//
+// Everything the denoiser forward needs is one of:
+//   gemm_k        fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM  C = epi( pro(A) @ W + bias )
+//                 pro : optional LayerNorm(+ReLU/GELU) of the A rows from precomputed (mean, rstd)
+//                 CONV: the k=7 dilated ByteNet convolution as 7 row-shifted tap GEMMs, zero outside
+//                       the chain segment (model/encoder/model.py:170-180 via sequence_models MaskedConv1d)
+//                 epi : + bias, activation, + residual, functional dropout (generated or injected),
+//                       + post-dropout addend, strided store
+//   attn_k        RoPE + softmax(QK^T/8) V for one (row, head): K/V staged in LDS, S^T = K Q^T kept in
+//                 MFMA accumulators (16x16x4 f32) so the softmax is lane-local and P feeds PV directly
+//                 (model/encoder/cross_attention.py:149-173)
+//   row_stats_k   per-row (mean, rstd) for LayerNorm, one wave per row, two-pass
+//   small kernels token gather, region/position/side embedding, final LN+decoder+exponential-race
+//                 sampling (antibody_scripts/sample.py:510-513), full decoder for hd_forward
+//
+// Activation rows live in "segment-major" order: all heavy-chain rows [B,152,C] first, then all
+// light-chain rows [B,139,C]; ByteNet stacks have separate weights per chain, so a GEMM tile never
+// mixes chains.  Segs::row(b, slot) is the only place that knows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { DROP_NONE = 0, DROP_GEN = 1, DROP_INJECT = 2 };
+
+struct Segs {
+    int nseg;      // 1 (nanobody) or 2 (antibody: heavy, light)
+    int B;         // rows (sequences) in the batch
+    int L;         // slots per sequence
+    int len[2];    // slots in segment
+    int off[2];    // first slot of segment
+    int base[2];   // first activation row of segment  (base[1] = B * len[0])
+    __host__ __device__ inline int row(int b, int slot) const {
+        int s = (nseg > 1 && slot >= off[1]) ? 1 : 0;
+        return base[s] + b * len[s] + (slot - off[s]);
+    }
+    __host__ __device__ inline int rows() const { return B * L; }
+};
+
+// Device-resident per-run state; kernels read it so that a captured hipGraph can be replayed per step.
+struct RunState {
+    uint32_t step;
+    uint32_t seed_lo, seed_hi;
+    uint32_t row0;
+    uint32_t pad[4];
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53U, c0), lo0 = 0xD2511F53U * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57U, c2), lo1 = 0xCD9E8D57U * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9U; k1 += 0xBB67AE85U;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+    if (act == ACT_RELU) return fmaxf(x, 0.0f);
+    if (act == ACT_GELU) return gelu_f(x);
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM
+// ------------------------------------------------------------------------------------------------
+struct GemmP {
+    // operands
+    const float* A; int lda;          // [rows, Kc] activation (segment-major rows)
+    const float* W;                   // [taps*Kc, N] row-major, per segment at + seg * w_stride
+    const float* bias;                // [N], per segment at + seg * n_stride (may be null)
+    float* C; int ldc;                // [rows, N]
+    int N, Kc, taps, dil;             // K = taps * Kc
+    long w_stride; int n_stride; int k_stride;   // per-segment strides of W / bias / (gamma, beta)
+    // prologue: LayerNorm over the Kc features of each A row, then activation
+    const float2* stats;              // [rows] (mean, rstd) or null
+    const float* gamma; const float* beta;
+    int pro_act;
+    // epilogue
+    int epi_act;
+    const float* resid; int ldr;      // added before dropout (may alias C)
+    const float* extra; int lde;      // added after dropout
+    int drop_mode; uint32_t drop_thresh; float drop_scale; uint32_t drop_site;
+    const uint8_t* drop_mask;         // [B, L, N] keep-mask (DROP_INJECT)
+    const RunState* rs;
+    // geometry
+    Segs sg;
+    int tiles0;                       // number of M tiles of segment 0
+};
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
+    constexpr int BK = 16;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AIT = (BM * 4 + 255) / 256, BIT = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int bx = blockIdx.x, seg = 0;
+    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+    const int Lc = p.sg.len[seg];
+    const int seg_rows = p.sg.B * Lc;
+    const int rbase = p.sg.base[seg];
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const float* __restrict__ W = p.W + (long)seg * p.w_stride;
+    const float* __restrict__ gamma = p.gamma ? p.gamma + seg * p.k_stride : nullptr;
+    const float* __restrict__ beta = p.beta ? p.beta + seg * p.k_stride : nullptr;
+    const int N = p.N, Kc = p.Kc;
+    const bool has_ln = p.stats != nullptr;
+    const int nkt_tap = (Kc + BK - 1) / BK;
+    const int nkt = nkt_tap * p.taps;
+    const int half = (p.taps - 1) / 2;
+
+    // per-thread A rows (fixed over the K loop)
+    int a_r[AIT], a_kq[AIT], a_pos[AIT];
+    bool a_ok[AIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        int idx = tid + 256 * i;
+        a_r[i] = idx >> 2; a_kq[i] = idx & 3;
+        int lrow = m0 + a_r[i];
+        a_ok[i] = (idx < BM * 4) && (lrow < seg_rows);
+        a_pos[i] = CONV ? (lrow % Lc) : 0;
+    }
+
+    f32x4 ra[AIT], rg[AIT], rb[AIT], rw[BIT];
+    float2 rst[AIT];
+    bool rav[AIT];
+
+    auto fetch = [&](int kt) {
+        const int tap = CONV ? kt / nkt_tap : 0;
+        const int kk0 = (CONV ? kt % nkt_tap : kt) * BK;
+        const int shift = CONV ? (tap - half) * p.dil : 0;
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int col = kk0 + 4 * a_kq[i];
+            bool v = a_ok[i] && col < Kc;
+            if (CONV) { int sp = a_pos[i] + shift; v = v && sp >= 0 && sp < Lc; }
+            rav[i] = v;
+            const long srow = (long)rbase + m0 + a_r[i] + shift;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[i] = z; rg[i] = z; rb[i] = z; rst[i] = make_float2(0.f, 0.f);
+            if (v) {
+                ra[i] = *reinterpret_cast<const f32x4*>(p.A + srow * p.lda + col);
+                if (has_ln) {
+                    rst[i] = p.stats[srow];
+                    rg[i] = *reinterpret_cast<const f32x4*>(gamma + col);
+                    rb[i] = *reinterpret_cast<const f32x4*>(beta + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            int idx = tid + 256 * i;
+            int kr = idx / (BN / 4), nq = idx % (BN / 4);
+            int ncol = n0 + 4 * nq;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rw[i] = z;
+            if (idx < BN * 4 && kk0 + kr < Kc && ncol < N)
+                rw[i] = *reinterpret_cast<const f32x4*>(W + (long)(tap * Kc + kk0 + kr) * N + ncol);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            if (tid + 256 * i < BM * 4) {
+                f32x4 v = ra[i];
+                if (has_ln) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        v[c] = act_f((v[c] - rst[i].x) * rst[i].y * rg[i][c] + rb[i][c], p.pro_act);
+                    if (!rav[i]) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) As[buf][4 * a_kq[i] + c][a_r[i]] = v[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            int idx = tid + 256 * i;
+            if (idx < BN * 4) {
+                int kr = idx / (BN / 4), nq = idx % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[buf][kr][4 * nq]) = rw[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    const int arow = wm * (BM / WM) + (lane & 31);
+    const int bcol = wn * (BN / WN) + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * ks + khalf][arow + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][2 * ks + khalf][bcol + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) commit(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------
+    const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
+    uint32_t k0 = 0, k1 = 0, row0 = 0;
+    if (p.drop_mode == DROP_GEN) {
+        uint32_t o[4];
+        philox4x32_10(0u, 0u, p.rs->step, p.drop_site, p.rs->seed_lo, p.rs->seed_hi, o);
+        k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (lrow >= seg_rows) continue;
+            const long grow = (long)rbase + lrow;
+            int b = 0, slot = 0;
+            uint32_t rk = 0;
+            if (p.drop_mode != DROP_NONE) {
+                b = lrow / Lc;
+                slot = p.sg.off[seg] + (lrow - b * Lc);
+                if (p.drop_mode == DROP_GEN) rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / WN) + 32 * j + (lane & 31);
+                if (col >= N) continue;
+                float v = acc[i][j][r];
+                if (bias) v += bias[col];
+                v = act_f(v, p.epi_act);
+                if (p.resid) v += p.resid[grow * p.ldr + col];
+                if (p.drop_mode == DROP_GEN) {
+                    uint32_t w = mix32(rk + (uint32_t)(slot * N + col) * 0x9E3779B9U);
+                    v = (w >= p.drop_thresh) ? v * p.drop_scale : 0.f;
+                } else if (p.drop_mode == DROP_INJECT) {
+                    uint8_t keep = p.drop_mask[((long)b * p.sg.L + slot) * N + col];
+                    v = keep ? v * p.drop_scale : 0.f;
+                }
+                if (p.extra) v += p.extra[grow * p.lde + col];
+                p.C[grow * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm statistics: one wave per row, two-pass (mean, then centred variance), eps = 1e-5
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) row_stats_k(const float* __restrict__ X, int ldx, int C, int rows,
+                                                    float2* __restrict__ stats) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (long)row * ldx;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { float d = v[k] - mean; q += d * d; }
+    }
+    const float var = wave_sum(q) / (float)C;
+    if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token embedding gather: X[row(b,l), :] = emb[tokens[b,l], :]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_tokens_k(const int32_t* __restrict__ tokens,
+                                                       const float* __restrict__ emb, int d,
+                                                       float* __restrict__ X, Segs sg) {
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (bl >= sg.B * sg.L) return;
+    const int b = bl / sg.L, l = bl - b * sg.L;
+    const float* e = emb + (long)tokens[bl] * d;
+    float* x = X + (long)sg.row(b, l) * d;
+    for (int c = lane * 4; c < d; c += 256)
+        *reinterpret_cast<f32x4*>(x + c) = *reinterpret_cast<const f32x4*>(e + c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Region branch up to "+ sinusoid PE" (RegionEmbedder model.py:222-230 + PositionalEncoding :80-87):
+//   x = ReLU(LN_d(W(ReLU(LN_re(emb[region]))) + b)) + pe[l]
+// one wave per (b, l); d <= 512, r_embedding <= 8.
+// ------------------------------------------------------------------------------------------------
+struct RegionW {
+    const float* emb;                       // [n_region, re]
+    const float* ln0_g; const float* ln0_b; // [re]
+    const float* w; const float* b;         // [re, d] (transposed), [d]
+    const float* ln1_g; const float* ln1_b; // [d]
+    const float* pe;                        // [L, d]
+};
+__global__ void __launch_bounds__(256) region_embed_k(const int32_t* __restrict__ region, RegionW w, int re,
+                                                       int d, float* __restrict__ X, Segs sg) {
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (bl >= sg.B * sg.L) return;
+    const int b = bl / sg.L, l = bl - b * sg.L;
+    float e[8];
+    float m = 0.f;
+    const float* er = w.emb + (long)region[bl] * re;
+    for (int k = 0; k < re; ++k) { e[k] = er[k]; m += e[k]; }
+    m /= (float)re;
+    float var = 0.f;
+    for (int k = 0; k < re; ++k) { float t = e[k] - m; var += t * t; }
+    const float rstd = 1.0f / sqrtf(var / (float)re + 1e-5f);
+    for (int k = 0; k < re; ++k) e[k] = fmaxf((e[k] - m) * rstd * w.ln0_g[k] + w.ln0_b[k], 0.f);
+    float y[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = lane + 64 * i;
+        y[i] = 0.f;
+        if (c < d) {
+            float a = w.b[c];
+            for (int k = 0; k < re; ++k) a += e[k] * w.w[k * d + c];
+            y[i] = a; s += a;
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { int c = lane + 64 * i; if (c < d) { float t = y[i] - mean; q += t * t; } }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    float* x = X + (long)sg.row(b, l) * d;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = lane + 64 * i;
+        if (c < d) x[c] = fmaxf((y[i] - mean) * rs * w.ln1_g[c] + w.ln1_b[c], 0.f) + w.pe[(long)l * d + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Side branch (SideEmbedder model.py:197-205) for each of the n_side chain types:
+//   vec[c] = W2 ReLU(LN(W1 emb[c] + b1)) + b2      one block per chain type, d <= 1024
+// ------------------------------------------------------------------------------------------------
+struct SideW {
+    const float* emb;                      // [n_side, se]
+    const float* w1; const float* b1;      // [se, d], [d]
+    const float* ln_g; const float* ln_b;  // [d]
+    const float* w2; const float* b2;      // [d, d] (in, out), [d]
+};
+__global__ void __launch_bounds__(256) side_vec_k(SideW w, int se, int d, float* __restrict__ vec) {
+    __shared__ float h[1024];
+    __shared__ float red[8];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int j = tid; j < d; j += 256) {
+        float a = w.b1[j];
+        for (int k = 0; k < se; ++k) a += w.emb[c * se + k] * w.w1[k * d + j];
+        h[j] = a; s += a;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float q = 0.f;
+    for (int j = tid; j < d; j += 256) { float t = h[j] - mean; q += t * t; }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+    for (int j = tid; j < d; j += 256) h[j] = fmaxf((h[j] - mean) * rs * w.ln_g[j] + w.ln_b[j], 0.f);
+    __syncthreads();
+    for (int j = tid; j < d; j += 256) {
+        float a = w.b2[j];
+        for (int k = 0; k < d; ++k) a += h[k] * w.w2[(long)k * d + j];
+        vec[(long)c * d + j] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Static (token-independent) part of the feature (AntiTFNet._encoder model.py:351-359):
+//   extra[row] = pos[row] (+ chn)      -> added to the token-encoder output every step
+//   feat[row, d:2d] = pos ; feat[row, 2d:3d] = chn (antibody)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) static_feature_k(const float* __restrict__ pos,
+                                                         const float* __restrict__ side_vec,
+                                                         const int32_t* __restrict__ chain, int d, int D,
+                                                         float* __restrict__ extra, float* __restrict__ feat,
+                                                         Segs sg) {
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (bl >= sg.B * sg.L) return;
+    const int b = bl / sg.L, l = bl - b * sg.L;
+    const long row = sg.row(b, l);
+    const float* sv = nullptr;
+    if (side_vec) {
+        int seg = (sg.nseg > 1 && l >= sg.off[1]) ? 1 : 0;
+        sv = side_vec + (long)chain[seg * sg.B + b] * d;
+    }
+    for (int c = lane; c < d; c += 64) {
+        float pv = pos[row * d + c];
+        float cv = sv ? sv[c] : 0.f;
+        extra[row * d + c] = pv + cv;
+        feat[row * D + d + c] = pv;
+        if (sv) feat[row * D + 2 * d + c] = cv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention for one (sequence, head): head_dim = 64, all L keys, no mask (cross_attention.py:149-173).
+// K (RoPE applied) and V live in LDS; per 16-query tile the wave keeps S^T[key, q] = K Q^T in 16x16x4
+// MFMA accumulators: lane (q = lane & 15, g = lane >> 4) owns keys 16*kt + 4*g + r, so max / sum over
+// keys is in-lane plus two xor-shuffles and exp(S) is already the B operand of O^T = V^T P^T.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_HD = 64;
+constexpr int ATT_KS = 68;   // K row stride in LDS (floats): 16-B aligned, spreads ds_read_b128 banks
+constexpr int ATT_VS = 64;
+constexpr int ATT_MAX_KT = 19;   // ceil(291 / 16)
+
+template <int NKT>
+__global__ void __launch_bounds__(256, 1) attn_k(const float* __restrict__ QKV, int ldq, int att,
+                                                  const float* __restrict__ rope_cos,
+                                                  const float* __restrict__ rope_sin,
+                                                  float* __restrict__ O, int ldo, int nhead, Segs sg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = sg.L;
+    float* Ks = smem;
+    float* Vs = smem + (size_t)L * ATT_KS;
+    const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
+
+    // ---- stage K (rotated) and V ------------------------------------------------------------
+    for (int idx = tid; idx < L * 16; idx += 256) {
+        const int key = idx >> 4, c4 = (idx & 15) * 4;
+        const long row = sg.row(b, key);
+        f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + koff + c4);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + voff + c4);
+        const float2 cs = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
+        const float2 sn = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
+        f32x4 kr;
+        kr[0] = kv[0] * cs.x - kv[1] * sn.x; kr[1] = kv[0] * sn.x + kv[1] * cs.x;
+        kr[2] = kv[2] * cs.y - kv[3] * sn.y; kr[3] = kv[2] * sn.y + kv[3] * cs.y;
+        *reinterpret_cast<f32x4*>(Ks + key * ATT_KS + c4) = kr;
+        *reinterpret_cast<f32x4*>(Vs + key * ATT_VS + c4) = vv;
+    }
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const int nqt = (L + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + qi;
+        const int qc = q < L ? q : L - 1;
+        const long qrow = sg.row(b, qc);
+        // Q fragment (B operand): lane holds Q[q][16 s + 4 g + c], rotated and pre-scaled by 1/8
+        f32x4 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c4 = 16 * s + 4 * g;
+            f32x4 v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
+            const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
+            const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
+            qf[s][0] = (v[0] * cs.x - v[1] * sn.x) * 0.125f; qf[s][1] = (v[0] * sn.x + v[1] * cs.x) * 0.125f;
+            qf[s][2] = (v[2] * cs.y - v[3] * sn.y) * 0.125f; qf[s][3] = (v[2] * sn.y + v[3] * cs.y) * 0.125f;
+        }
+        // S^T tiles
+        f32x4 st[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            int key = kt * 16 + qi;                     // A operand row index i = lane & 15
+            key = key < L ? key : L - 1;
+            const float* kp = Ks + key * ATT_KS + 4 * g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 16 * s);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[s][c], acc, 0, 0, 0);
+            }
+            st[kt] = acc;
+            __builtin_amdgcn_sched_barrier(0);   // keep later tiles' LDS reads from being hoisted (VGPR pressure)
+        }
+        // softmax over keys (rows of S^T); this lane owns keys 16 kt + 4 g + r
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float e = expf(st[kt][r] - mx); st[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // O^T[d, q] = sum_key V[key, d] P[key, q]
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; oacc[dt] = z; }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kt * 16 + 4 * g + r;
+                key = key < L ? key : L - 1;            // P is exactly 0 there
+                const float* vp = Vs + key * ATT_VS + qi;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * dt], st[kt][r], oacc[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = oacc[dt];
+                o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+                *reinterpret_cast<f32x4*>(O + qrow * ldo + h * ATT_HD + 16 * dt + 4 * g) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final stage of a sampling step (sample.py:508-513): for row b at its slot of this step,
+//   logits = Linear(LN(h[row]))[0:22]; p = softmax(logits); s = argmax p / q; tokens[b, slot] = s
+// one wave per sequence.  D <= 1024.
+// ------------------------------------------------------------------------------------------------
+struct HeadW {
+    const float* ln_g; const float* ln_b;   // last_norm [D]
+    const float* w; const float* b;         // decoder.weight [n_tokens, D] (torch layout), bias [n_tokens]
+};
+__device__ __forceinline__ void ln_row_regs(const float* __restrict__ x, int D, int lane, const HeadW& w,
+                                            float (&y)[16]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; y[i] = (c < D) ? x[c] : 0.f; s += y[i]; }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; if (c < D) { float t = y[i] - mean; q += t * t; } }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int c = lane + 64 * i;
+        y[i] = (c < D) ? (y[i] - mean) * rs * w.ln_g[c] + w.ln_b[c] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm, int D, HeadW w,
+                                                     int32_t* __restrict__ tokens,
+                                                     const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ T, int Tmax,
+                                                     const float* __restrict__ q_noise,
+                                                     const RunState* __restrict__ rs, Segs sg) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t t = rs->step;
+    if ((int)t >= T[b]) return;
+    const int slot = order[(long)b * Tmax + t];
+    float y[16];
+    ln_row_regs(Hm + (long)sg.row(b, slot) * D, D, lane, w, y);
+    float mylogit = -INFINITY;
+    for (int j = 0; j < 22; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; if (c < D) a += y[i] * w.w[(long)j * D + c]; }
+        a = wave_sum(a) + w.b[j];
+        if (lane == j) mylogit = a;
+    }
+    const float mx = wave_max(mylogit);
+    const float e = (lane < 22) ? expf(mylogit - mx) : 0.f;
+    const float p = e / wave_sum(e);
+    float q = 1.f;
+    if (lane < 22) {
+        if (q_noise) {
+            q = q_noise[((long)t * sg.B + b) * 22 + lane];
+        } else {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)lane >> 2, rs->row0 + (uint32_t)b, t, 0xFFFFFFFFU, rs->seed_lo, rs->seed_hi, o);
+            const float u = ((float)(o[lane & 3] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+            q = -logf(u);
+        }
+    }
+    float ratio = (lane < 22) ? p / q : -INFINITY;
+    int best = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float r2 = __shfl_xor(ratio, o);
+        int b2 = __shfl_xor(best, o);
+        if (r2 > ratio || (r2 == ratio && b2 < best)) { ratio = r2; best = b2; }
+    }
+    if (lane == 0) tokens[(long)b * sg.L + slot] = best;
+}
+
+// Full decoder for hd_forward: logits[b, l, :] = Linear(LN(h[row(b,l)])) , one wave per (b, l).
+__global__ void __launch_bounds__(256) decode_all_k(const float* __restrict__ Hm, int D, HeadW w, int n_tokens,
+                                                     float* __restrict__ logits, Segs sg) {
+    const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (bl >= sg.B * sg.L) return;
+    const int b = bl / sg.L, l = bl - b * sg.L;
+    float y[16];
+    ln_row_regs(Hm + (long)sg.row(b, l) * D, D, lane, w, y);
+    for (int j = 0; j < n_tokens; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; if (c < D) a += y[i] * w.w[(long)j * D + c]; }
+        a = wave_sum(a) + w.b[j];
+        if (lane == 0) logits[(long)bl * n_tokens + j] = a;
+    }
+}
+
+__global__ void set_step_k(RunState* rs, uint32_t step) { rs->step = step; }
+__global__ void advance_step_k(RunState* rs) { rs->step += 1; }
+
+}  // namespace hd

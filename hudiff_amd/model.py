@@ -1,0 +1,258 @@
+"""Host-side mirror of the reference's model-call boundary, backed by libhudiff_hip.so.
+
+Reference interface mirrored (file:line under /root/reference):
+  * ``AntiTFNet(**config.model)`` / ``NanoAntiTFNet(**config.model)``   model/encoder/model.py:325-349,
+    model/nanoencoder/model.py:290-311 -- same constructor keywords
+  * ``model_selected(config)``                                          utils/train_utils.py:43-55
+  * ``model.load_state_dict(ckpt['model'])`` / ``.eval()`` / ``.to(device)``   antibody_scripts/sample.py:456-458
+  * ``model(H_L_seq, H_L_region_type, H_L_chn_type) -> logits[B, L, n_tokens]``  model/encoder/model.py:366-384
+so the reference-shaped loop (sample.py:499-513) can drive it unchanged; ``.sample`` runs the whole loop
+on the device (hd_sample).  torch is used only to read checkpoints / to hand tensors back in the
+caller's type -- no torch op is on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+_ACT = {"relu": L.HD_ACT_RELU, "gelu": L.HD_ACT_GELU}
+AB_H_LEN = 152
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, Mapping):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _to_numpy(x):
+    if x is None:
+        return None, False
+    if hasattr(x, "detach") and hasattr(x, "cpu"):       # torch.Tensor without importing torch
+        return x.detach().cpu().numpy(), True
+    return np.asarray(x), False
+
+
+class _Denoiser:
+    kind = None            # 'ab' | 'nb'
+
+    def __init__(self, n_tokens, d_embedding, d_model, n_encoder_layers, aa_kernel_size, r,
+                 n_region, r_embedding, r_model, n_pos_model, max_len, sum_d_model, dual_layers,
+                 att_model, dim_feedforward, nhead, cs_layers, n_side=3, s_embedding=4, s_model=None,
+                 rank=None, n_frozen_embs=None, padding_idx=None, causal=False, dropout=0.0, slim=True,
+                 activation="relu", down_embed=False, timesteps=None, device=0):
+        if rank is not None or n_frozen_embs is not None or causal or not slim or down_embed or padding_idx is not None:
+            raise NotImplementedError("only the configuration HuDiff ships (rank=None, causal=False, slim=True, "
+                                      "down_embed=False, padding_idx=None) is implemented")
+        if not (d_embedding == d_model == r_model == n_pos_model) or (s_model not in (None, d_model)):
+            raise ValueError("d_embedding, d_model, r_model, n_pos_model (and s_model) must be equal")
+        self.config = dict(n_tokens=n_tokens, d_embedding=d_embedding, d_model=d_model,
+                           n_encoder_layers=n_encoder_layers, aa_kernel_size=aa_kernel_size, r=r,
+                           n_region=n_region, r_embedding=r_embedding, r_model=r_model, n_pos_model=n_pos_model,
+                           max_len=max_len, sum_d_model=sum_d_model, dual_layers=dual_layers, att_model=att_model,
+                           dim_feedforward=dim_feedforward, nhead=nhead, cs_layers=cs_layers, dropout=float(dropout),
+                           activation=activation)
+        if self.kind == "ab":
+            self.config.update(n_side=n_side, s_embedding=s_embedding, s_model=d_model)
+        c = L.HdConfig()
+        c.abi_version = L.HD_ABI_VERSION
+        c.kind = L.HD_KIND_ANTIBODY if self.kind == "ab" else L.HD_KIND_NANOBODY
+        c.n_tokens, c.max_len = n_tokens, max_len
+        c.h_len = AB_H_LEN if self.kind == "ab" else max_len
+        c.d_model, c.sum_d_model = d_model, sum_d_model
+        c.n_encoder_layers, c.dual_layers, c.kernel_size, c.r = n_encoder_layers, dual_layers, aa_kernel_size, r
+        c.att_model, c.nhead, c.dim_feedforward, c.cs_layers = att_model, nhead, dim_feedforward, cs_layers
+        c.n_region, c.r_embedding = n_region, r_embedding
+        c.n_side, c.s_embedding = (n_side, s_embedding) if self.kind == "ab" else (0, 0)
+        c.enc_act = _ACT[activation]
+        # DualConv is constructed with its default activation='relu' (model/encoder/model.py:345),
+        # NanoConv with its default 'gelu' (model/nanoencoder/model.py:242, 308)
+        c.conv_act = L.HD_ACT_RELU if self.kind == "ab" else L.HD_ACT_GELU
+        c.dropout = float(dropout)
+        self._cfg = c
+        self.max_len, self.n_tokens = max_len, n_tokens
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self._lib.hd_create(C.byref(c), int(device), C.byref(self._h)))
+        self._loaded = False
+        self.device_index = int(device)
+
+    # -- nn.Module-shaped surface ---------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        if self._loaded:
+            raise RuntimeError("weights already loaded into this handle")
+        if not strict:
+            raise NotImplementedError("strict=False is not supported")
+        for key, val in state_dict.items():
+            if hasattr(val, "is_complex") and val.is_complex():       # '...rope' buffers: recomputed
+                continue
+            arr, _ = _to_numpy(val)
+            if np.iscomplexobj(arr):
+                continue
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            L.check(self._lib.hd_load_tensor(self._h, key.encode(), L.ptr(arr, C.c_float), shape, arr.ndim))
+        L.check(self._lib.hd_finalize(self._h))
+        self._loaded = True
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _prep(self, tokens, region, chain):
+        tok, was_torch = _to_numpy(tokens)
+        reg, _ = _to_numpy(region)
+        chn, _ = _to_numpy(chain)
+        if tok.ndim != 2 or tok.shape[1] != self.max_len:
+            # the reference asserts L == rolength in RoPE (cross_attention.py:29-30)
+            raise AssertionError(f"tokens must be [B, {self.max_len}], got {tok.shape}")
+        B = tok.shape[0]
+        tok = L.as_i32(tok)
+        reg = L.as_i32(reg, (B, self.max_len))
+        if self.kind == "ab":
+            if chn is None:
+                raise ValueError("AntiTFNet needs H_L_chn_type [2B]")
+            chn = L.as_i32(np.asarray(chn).reshape(-1), (2 * B,))
+        else:
+            chn = None
+        return tok, reg, chn, B, was_torch
+
+    @staticmethod
+    def _flags(dropout, graph=True):
+        f = {"faithful": L.HD_DROPOUT_FAITHFUL, "off": L.HD_DROPOUT_OFF, "inject": L.HD_DROPOUT_INJECT}[dropout]
+        return f | (0 if graph else L.HD_NO_GRAPH)
+
+    def forward(self, H_L_seq, H_L_region_type, H_L_chn_type=None, *, dropout="faithful", seed=0, row0=0,
+                step=0, enc_masks=None, conv_masks=None):
+        if not self._loaded:
+            raise RuntimeError("load_state_dict first")
+        tok, reg, chn, B, was_torch = self._prep(H_L_seq, H_L_region_type, H_L_chn_type)
+        logits = np.empty((B, self.max_len, self.n_tokens), dtype=np.float32)
+        em = None if enc_masks is None else np.ascontiguousarray(enc_masks, dtype=np.uint8)
+        cm = None if conv_masks is None else np.ascontiguousarray(conv_masks, dtype=np.uint8)
+        L.check(self._lib.hd_forward(self._h, L.ptr(tok, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
+                                     B, self._flags(dropout), int(seed), int(row0), int(step),
+                                     L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8), L.ptr(logits, C.c_float)))
+        if was_torch:
+            import torch
+            return torch.from_numpy(logits)
+        return logits
+
+    __call__ = forward
+
+    # -- whole loop on the device ----------------------------------------------------------------
+    def _sample_args(self, tokens, region, chain, order, T, q_noise, enc_masks, conv_masks):
+        tok, reg, chn, B, was_torch = self._prep(tokens, region, chain)
+        order = np.asarray(order)
+        Tmax = int(order.shape[1]) if order.ndim == 2 else 0
+        order = L.as_i32(order.reshape(B, Tmax), (B, Tmax))
+        T = L.as_i32(np.asarray(T).reshape(-1), (B,))
+        q = None if q_noise is None else np.ascontiguousarray(q_noise, dtype=np.float32)
+        if q is not None and q.shape != (Tmax, B, 22):
+            raise ValueError(f"q_noise must be [{Tmax}, {B}, 22], got {q.shape}")
+        em = None if enc_masks is None else np.ascontiguousarray(enc_masks, dtype=np.uint8)
+        cm = None if conv_masks is None else np.ascontiguousarray(conv_masks, dtype=np.uint8)
+        return tok, reg, chn, order, T, B, Tmax, q, em, cm, was_torch
+
+    def sample(self, tokens, region, chain, order, T, *, seed=0, row0=0, q_noise=None, dropout="faithful",
+               enc_masks=None, conv_masks=None, graph=True):
+        """Run the T-step loop (sample.py:499-513) for B independent rows; returns the filled tokens."""
+        tok, reg, chn, order, T, B, Tmax, q, em, cm, was_torch = self._sample_args(
+            tokens, region, chain, order, T, q_noise, enc_masks, conv_masks)
+        out = tok.copy()
+        L.check(self._lib.hd_sample(self._h, L.ptr(out, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
+                                    L.ptr(order, C.c_int32), L.ptr(T, C.c_int32), B, Tmax,
+                                    self._flags(dropout, graph), int(seed), int(row0), L.ptr(q, C.c_float),
+                                    L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8)))
+        if was_torch:
+            import torch
+            return torch.from_numpy(out.astype(np.int64))
+        return out
+
+    def sample_begin(self, tokens, region, chain, order, T, *, seed=0, row0=0, q_noise=None, dropout="faithful",
+                     enc_masks=None, conv_masks=None, graph=True):
+        tok, reg, chn, order, T, B, Tmax, q, em, cm, _ = self._sample_args(
+            tokens, region, chain, order, T, q_noise, enc_masks, conv_masks)
+        L.check(self._lib.hd_sample_begin(self._h, L.ptr(tok, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
+                                          L.ptr(order, C.c_int32), L.ptr(T, C.c_int32), B, Tmax,
+                                          self._flags(dropout, graph), int(seed), int(row0), L.ptr(q, C.c_float),
+                                          L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8)))
+        self._session_B = B
+
+    def sample_run(self, t0, t1):
+        L.check(self._lib.hd_sample_run(self._h, int(t0), int(t1)))
+
+    def sync(self):
+        L.check(self._lib.hd_sync(self._h))
+
+    def sample_end(self):
+        out = np.empty((self._session_B, self.max_len), dtype=np.int32)
+        L.check(self._lib.hd_sample_end(self._h, L.ptr(out, C.c_int32)))
+        return out
+
+    def last_run_ms(self):
+        ms, steps = C.c_float(), C.c_int32()
+        L.check(self._lib.hd_last_run_ms(self._h, C.byref(ms), C.byref(steps)))
+        return float(ms.value), int(steps.value)
+
+    def flops_per_row_forward(self):
+        return float(self._lib.hd_flops_per_row_forward(C.byref(self._cfg)))
+
+
+class AntiTFNet(_Denoiser):
+    """model/encoder/model.py:325 -- antibody (VH + VL, 291 slots) denoiser."""
+    kind = "ab"
+
+
+class NanoAntiTFNet(_Denoiser):
+    """model/nanoencoder/model.py:290 -- nanobody (VHH, 152 slots) denoiser."""
+    kind = "nb"
+
+    def __init__(self, n_tokens, d_embedding, d_model, n_encoder_layers, aa_kernel_size, r, n_region, r_embedding,
+                 r_model, n_pos_model, max_len, sum_d_model, dual_layers, att_model, dim_feedforward, nhead, cs_layers,
+                 **kw):
+        super().__init__(n_tokens, d_embedding, d_model, n_encoder_layers, aa_kernel_size, r, n_region, r_embedding,
+                         r_model, n_pos_model, max_len, sum_d_model, dual_layers, att_model, dim_feedforward, nhead,
+                         cs_layers, **kw)
+
+
+def model_selected(config, pretrained_model=None, tokenizer=None, device=0):
+    """utils/train_utils.py:43-55 for the two inference models (the training-only wrappers are out of scope)."""
+    name = _get(config, "name")
+    params = dict(_get(config, "model"))
+    if name == "trans_oadm":
+        return AntiTFNet(**params, device=device)
+    if name == "nano":
+        return NanoAntiTFNet(**params, device=device)
+    raise NotImplementedError(f"config.name={name!r}: only 'trans_oadm' and 'nano' are sampling models")
+
+
+def device_info(device=0):
+    lib = L.load()
+    name = C.create_string_buffer(256)
+    cu, mem = C.c_int32(), C.c_int64()
+    L.check(lib.hd_device_info(int(device), name, 256, C.byref(cu), C.byref(mem)))
+    return {"name": name.value.decode(), "cu_count": int(cu.value), "hbm_bytes": int(mem.value)}
+
+
+def device_count():
+    return int(L.load().hd_device_count())

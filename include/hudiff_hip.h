@@ -1,0 +1,156 @@
+/*
+ * hudiff_hip.h -- C ABI of libhudiff_hip.so: HuDiff's denoiser forward + T-step sampling loop on
+ * MI355X (gfx950), hand-written HIP.  This is the drop-in boundary for ONE path of the reference:
+ *
+ *   reference interface replaced                          (file:line under /root/reference)
+ *   ------------------------------------------------------------------------------------------------
+ *   model_selected(config)  -> nn.Module                   utils/train_utils.py:43-55
+ *   model.load_state_dict(ckpt['model'])                   antibody_scripts/sample.py:456-458
+ *                                                          nanobody_scripts/nanosample.py:252-288
+ *   model(H_L_seq, H_L_region_type, H_L_chn_type)          model/encoder/model.py:366-384
+ *        -> logits[B, L, n_tokens]                         model/nanoencoder/model.py:325-343
+ *   the sampling loop (forward, softmax[:, i, :22],        antibody_scripts/sample.py:499-513
+ *        torch.multinomial, tokens[:, i] = s)              nanobody_scripts/nanosample.py:316-329
+ *
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.  Every function returns an
+ * HdStatus (0 = ok); hd_last_error() gives the message of the last failure on the calling thread.
+ * A handle is bound to one device and one HIP stream and is NOT re-entrant; use one handle per GPU.
+ * All tensors are caller-owned host memory unless a name ends in _dev; nothing is retained after return
+ * (except by hd_load_tensor, which copies).
+ *
+ * Row / slot conventions: L = cfg.max_len IMGT slots per row (291 = 152 heavy + 139 light for the
+ * antibody model, 152 for the nanobody model); tokens in [0,22] (utils/tokenizer.py:55-62: 20 residues,
+ * X=20, '-'=21, <msk>=22); region in [0, n_region); chain type in {0 (H), 1 (L), 2 (K)} laid out as
+ * chain[0:B] = heavy rows, chain[B:2B] = light rows (sample.py:172-176).
+ *
+ * Noise ("what makes sampled ids bit-exact under a fixed seed"):
+ *   sampling  s = argmax_j softmax(logits[slot, 0:22])_j / q_j   (first maximum wins), q ~ Exp(1).
+ *             q is either injected (q_noise) or generated:  Philox4x32-10, key = seed,
+ *             counter = (j >> 2, global_row, step, 0xFFFFFFFF), word j & 3,
+ *             u = ((w >> 8) + 0.5) * 2^-24,  q = -log(u).
+ *   dropout   (the reference runs F.dropout with training=True at inference whenever cfg.dropout > 0,
+ *             model/encoder/model.py:176-178, 295-303): keep-mask either injected or generated:
+ *             (k0, k1) = Philox4x32-10(counter = (0, 0, step, site), key = seed)[0:2],
+ *             rk = mix32(k0 ^ mix32(global_row + k1)),  w = mix32(rk + (slot * width + feature) * 0x9E3779B9),
+ *             keep <=> w >= floor(p * 2^32);  kept values are scaled by 1/(1-p).
+ *             site = layer for the token encoder (p = cfg.dropout), 64 + layer for Dual/NanoConv (p = 0.5).
+ *             mix32(x): x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16.
+ *   global_row = row0 + b, so results do not depend on how rows are sharded over GPUs.
+ */
+#ifndef HUDIFF_HIP_H
+#define HUDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HD_ABI_VERSION 1
+
+typedef enum HdStatus {
+    HD_OK = 0,
+    HD_ERR_INVALID = 1,      /* bad argument / value out of range (token, region, chain, L, ...) */
+    HD_ERR_UNSUPPORTED = 2,  /* configuration outside what the kernels implement                 */
+    HD_ERR_STATE = 3,        /* call order (e.g. forward before finalize, missing tensors)       */
+    HD_ERR_HIP = 4,          /* a HIP runtime call failed; message has the hipError string       */
+    HD_ERR_NO_DEVICE = 5     /* no usable gfx950 device: the product path never falls back to CPU */
+} HdStatus;
+
+enum { HD_KIND_ANTIBODY = 0, HD_KIND_NANOBODY = 1 };
+enum { HD_ACT_RELU = 1, HD_ACT_GELU = 2 };
+
+/* flags for hd_forward / hd_sample */
+enum {
+    HD_DROPOUT_FAITHFUL = 0u,  /* default: dropout active iff cfg.dropout > 0, generated masks      */
+    HD_DROPOUT_OFF      = 1u,  /* sites are identity                                                */
+    HD_DROPOUT_INJECT   = 2u,  /* caller supplies keep-masks (parity tests)                         */
+    HD_DROPOUT_MASK     = 3u,
+    HD_NO_GRAPH         = 4u   /* launch kernels eagerly instead of replaying the captured hipGraph */
+};
+
+/* Hyper-parameters: the `model:` section of configs/antibody_train.yml:3-24 / heavy_train.yml:3-21,
+ * i.e. what sample.py reads from ckpt['config'|'pretrain_config'].model. */
+typedef struct HdConfig {
+    int32_t abi_version;       /* HD_ABI_VERSION */
+    int32_t kind;              /* HD_KIND_* */
+    int32_t n_tokens;          /* 23 */
+    int32_t max_len;           /* 291 | 152 */
+    int32_t h_len;             /* heavy slots: 152 (antibody: light = max_len - h_len) ; nanobody: max_len */
+    int32_t d_model;           /* 256  (= d_embedding = s_model = r_model = n_pos_model) */
+    int32_t sum_d_model;       /* 768 | 512 */
+    int32_t n_encoder_layers;  /* 6 */
+    int32_t dual_layers;       /* 6 */
+    int32_t kernel_size;       /* 7 */
+    int32_t r;                 /* 128: dilation of layer n = 2^(n mod (log2(r)+1)) */
+    int32_t att_model;         /* 512 */
+    int32_t nhead;             /* 8  (att_model / nhead must be 64) */
+    int32_t dim_feedforward;   /* 256 */
+    int32_t cs_layers;         /* 5 */
+    int32_t n_region;          /* 7 */
+    int32_t r_embedding;       /* 4 */
+    int32_t n_side;            /* 3 (antibody only) */
+    int32_t s_embedding;       /* 4 (antibody only) */
+    int32_t enc_act;           /* HD_ACT_*: config.activation (token encoder)                        */
+    int32_t conv_act;          /* HD_ACT_*: relu for DualConv (model.py:345), gelu for NanoConv       */
+    float   dropout;           /* config.dropout */
+} HdConfig;
+
+typedef struct HdModel HdModel;
+
+/* ---- construction (replaces model_selected + load_state_dict) ---------------------------------- */
+int hd_device_count(void);
+HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out);
+/* One call per state_dict entry, `key` = the reference's own key, data = float32 in
+ * the torch layout ([out,in] Linear, [out,in,k] Conv1d).  Recomputable buffers ('...rope',
+ * 'pos_encoder.pos_embedding.pe') are accepted and ignored.  Unknown keys -> HD_ERR_INVALID (strict). */
+HdStatus hd_load_tensor(HdModel* m, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+/* Checks every required key was loaded with the right shape, re-lays weights for the kernels and uploads. */
+HdStatus hd_finalize(HdModel* m);
+void hd_destroy(HdModel* m);
+const char* hd_last_error(void);
+
+/* ---- one denoiser forward (replaces model(tokens, region, chain)) -------------------------------
+ * logits: [B, L, 23] float32.  chain: [2B] (antibody) or NULL (nanobody).
+ * enc_masks [n_encoder_layers, B, L, d_model], conv_masks [dual_layers, B, L, sum_d_model] uint8
+ * (1 = keep) are read only with HD_DROPOUT_INJECT.  seed/row0/step key generated masks. */
+HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                    int32_t B, uint32_t flags, uint64_t seed, uint64_t row0, uint32_t step,
+                    const uint8_t* enc_masks, const uint8_t* conv_masks, float* logits);
+
+/* ---- the whole T-step sampling loop (replaces sample.py:499-513) --------------------------------
+ * tokens [B, L] in/out.  order [B, Tmax]: slot visited by row b at step t; T [B]: steps of row b
+ * (rows with t >= T[b] are left untouched at step t; T[b] == 0 is allowed).
+ * q_noise [Tmax, B, 22] or NULL.  With HD_DROPOUT_INJECT: enc_masks [Tmax, n_enc, B, L, d],
+ * conv_masks [Tmax, n_conv, B, L, D]. */
+HdStatus hd_sample(HdModel* m, int32_t* tokens, const int32_t* region, const int32_t* chain,
+                   const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                   uint64_t seed, uint64_t row0, const float* q_noise,
+                   const uint8_t* enc_masks, const uint8_t* conv_masks);
+
+/* Split form of hd_sample so that a caller can time the device-resident part:
+ *   begin : validates, uploads inputs, computes the token-independent embedding branch
+ *   run   : enqueues steps [t0, t1) on the handle's stream and returns without synchronising
+ *   end   : synchronises and copies the tokens back                                                  */
+HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                         const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                         uint64_t seed, uint64_t row0, const float* q_noise,
+                         const uint8_t* enc_masks, const uint8_t* conv_masks);
+HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1);
+HdStatus hd_sample_end(HdModel* m, int32_t* tokens);
+HdStatus hd_sync(HdModel* m);
+
+/* ---- measurement helpers ------------------------------------------------------------------------
+ * hd_sample_run brackets the steps it enqueues with HIP events on the handle's stream;
+ * hd_last_run_ms returns the elapsed device time of the last completed run (after hd_sync/hd_sample_end). */
+HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps);
+/* Algorithmic FLOPs of one forward of one row (SURVEY.md §8d formula). */
+double hd_flops_per_row_forward(const HdConfig* cfg);
+/* Device facts for the bench JSON. */
+HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUDIFF_HIP_H */

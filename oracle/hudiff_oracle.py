@@ -49,8 +49,8 @@ AB_L_LEN = 139
 # --------------------------------------------------------------------------------------
 # Counter-based noise contract shared with the HIP library (include/hudiff_hip.h "Noise").
 # Philox4x32-10, key = (seed_lo, seed_hi).
-#   dropout : counter = (elem >> 2, global_row, step, site)        word = elem & 3
-#             elem = slot * width + feature ; keep  <=>  u32 >= floor(p * 2^32)
+#   dropout : (k0, k1) = Philox(counter = (0, 0, step, site))[0:2] ; rk = mix32(k0 ^ mix32(global_row + k1))
+#             w = mix32(rk + (slot * width + feature) * 0x9E3779B9) ; keep  <=>  w >= floor(p * 2^32)
 #             site = layer index for the token encoder, 64 + layer index for Dual/NanoConv
 #   sampling: counter = (j >> 2, global_row, step, 0xFFFFFFFF)     word = j & 3 , j in [0, 22)
 #             u = ((u32 >> 8) + 0.5) * 2^-24 ;  q = -log(u)  (float32)
@@ -83,18 +83,29 @@ def philox4x32(c0, c1, c2, c3, seed: int):
     return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
 
 
+def mix32(x):
+    """lowbias32 finaliser on uint32 arrays (wrap-around arithmetic)."""
+    x = np.asarray(x, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x
+
+
 def philox_keep_mask(seed: int, rows: np.ndarray, step: int, site: int, n_slots: int, width: int,
                      p: float) -> np.ndarray:
-    """uint8 keep-mask [len(rows), n_slots, width] for one dropout site."""
+    """uint8 keep-mask [len(rows), n_slots, width] for one dropout site (see the contract above)."""
+    k0, k1, _, _ = philox4x32(np.uint32(0), np.uint32(0), np.uint32(step), np.uint32(site), seed)
+    k0, k1 = np.uint64(int(k0)), np.uint64(int(k1))
+    m32 = np.uint64(0xFFFFFFFF)
+    rows = np.asarray(rows, dtype=np.uint64) & m32
+    rk = mix32(k0 ^ mix32((rows + k1) & m32))                            # [R]
     elem = np.arange(n_slots * width, dtype=np.uint64)
-    grp = (elem >> np.uint64(2)).astype(np.uint32)
-    out = philox4x32(grp[None, :], np.asarray(rows, dtype=np.uint32)[:, None], np.uint32(step),
-                     np.uint32(site), seed)
-    words = np.stack(out, axis=-1)                                   # [R, E, 4]
-    sel = (elem & np.uint64(3)).astype(np.int64)
-    u = np.take_along_axis(words, sel[None, :, None], axis=-1)[..., 0]
-    thresh = np.uint32(min(int(math.floor(p * 4294967296.0)), 0xFFFFFFFF))
-    return (u >= thresh).astype(np.uint8).reshape(len(rows), n_slots, width)
+    w = mix32((rk[:, None] + elem[None, :] * np.uint64(0x9E3779B9)) & m32)
+    thresh = np.uint64(min(int(math.floor(p * 4294967296.0)), 0xFFFFFFFF))
+    return (w >= thresh).astype(np.uint8).reshape(len(rows), n_slots, width)
 
 
 def philox_exp_noise(seed: int, rows: np.ndarray, step: int) -> np.ndarray:

@@ -1,0 +1,203 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors
+produced by the reference's own classes.
+
+Tolerances (north_star): logits within 1e-4 absolute of the reference CPU path; sampled token ids
+bit-exact under the same noise (injected Exp(1) noise / dropout masks, or the shared Philox contract).
+"""
+import numpy as np
+import pytest
+
+import hudiff_oracle as ho
+from conftest import chain_or_none, load_cfg, load_golden, load_weights, unpack_masks
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hudiff_amd
+    if hudiff_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: GPU tests must run on the GPU box (there is no CPU fallback)")
+    return hudiff_amd
+
+
+def _mk(hip, kind, cfg, sd):
+    cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
+    m = cls(**cfg)
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.fixture(scope="module", params=["ab", "nb"])
+def micro(request, hip):
+    kind = request.param
+    cfg, sd = load_cfg(kind), load_weights(kind)
+    p = 0.2 if kind == "ab" else 0.5
+    models = {"kind": kind, "cfg": cfg, "sd": sd,
+              "m0": _mk(hip, kind, cfg, sd), "m1": _mk(hip, kind, dict(cfg, dropout=p), sd),
+              "o0": ho.OracleNet(kind, cfg, sd), "o1": ho.OracleNet(kind, dict(cfg, dropout=p), sd), "p": p}
+    yield models
+    models["m0"].close(); models["m1"].close()
+
+
+def test_forward_matches_reference_golden(micro):
+    z = load_golden(f"micro_{micro['kind']}_forward.npz")
+    logits = micro["m0"](z["tokens"], z["region"], chain_or_none(z))
+    assert logits.shape == z["logits"].shape
+    assert np.abs(logits - z["logits"]).max() < LOGIT_TOL
+    assert np.abs(logits - micro["o0"](z["tokens"], z["region"], chain_or_none(z))).max() < LOGIT_TOL
+
+
+def test_forward_with_reference_dropout_masks(micro):
+    z = load_golden(f"micro_{micro['kind']}_forward_dropout.npz")
+    logits = micro["m1"](z["tokens"], z["region"], chain_or_none(z), dropout="inject",
+                         enc_masks=unpack_masks(z, "enc_masks"), conv_masks=unpack_masks(z, "conv_masks"))
+    assert np.abs(logits - z["logits"]).max() < LOGIT_TOL
+    off = micro["m1"](z["tokens"], z["region"], chain_or_none(z), dropout="off")
+    assert np.abs(off - z["logits"]).max() > 1e-2       # dropout really was applied in the reference run
+
+
+def test_forward_generated_dropout_matches_oracle_contract(micro):
+    z = load_golden(f"micro_{micro['kind']}_forward.npz")
+    B = z["tokens"].shape[0]
+    logits = micro["m1"](z["tokens"], z["region"], chain_or_none(z), dropout="faithful", seed=0x1234567890AB, row0=7, step=5)
+    want = micro["o1"](z["tokens"], z["region"], chain_or_none(z),
+                       dropout=ho.Dropout("philox", seed=0x1234567890AB, rows=np.arange(B) + 7, step=5))
+    assert np.abs(logits - want).max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("mode", ["finetune", "plain", "inpaint"])
+@pytest.mark.parametrize("graph", [True, False])
+def test_full_sampling_trace_bit_exact(micro, mode, graph):
+    if (micro["kind"] == "ab") != (mode == "finetune"):
+        pytest.skip("mode belongs to the other model")
+    z = load_golden(f"micro_{micro['kind']}_sample_{mode}.npz")
+    B, loc = z["tokens"].shape[0], z["loc"]
+    out = micro["m0"].sample(z["tokens"], z["region"], chain_or_none(z), np.repeat(loc[None], B, 0),
+                             np.full(B, len(loc)), q_noise=z["q"], graph=graph)
+    assert np.array_equal(out, z["final"])          # identical humanized residues as the reference loop
+
+
+def test_sampling_with_reference_dropout_masks(micro):
+    z = load_golden(f"micro_{micro['kind']}_sample_dropout.npz")
+    B, loc = z["tokens"].shape[0], z["loc"]
+    out = micro["m1"].sample(z["tokens"], z["region"], chain_or_none(z), np.repeat(loc[None], B, 0),
+                             np.full(B, len(loc)), q_noise=z["q"], dropout="inject",
+                             enc_masks=unpack_masks(z, "enc_masks"), conv_masks=unpack_masks(z, "conv_masks"))
+    assert np.array_equal(out, z["final"])
+
+
+def test_teacher_forced_steps(micro):
+    """Per-step parity: feed the reference's token state, compare logits at the visited slot and the draw."""
+    mode = "finetune" if micro["kind"] == "ab" else "plain"
+    z = load_golden(f"micro_{micro['kind']}_sample_{mode}.npz")
+    tokens = z["tokens"].copy()
+    B = tokens.shape[0]
+    for t, slot in enumerate(z["loc"][:40]):
+        logits = micro["m0"](tokens, z["region"], chain_or_none(z))[:, slot, :22]
+        assert np.abs(logits - z["step_logits"][t]).max() < LOGIT_TOL
+        s, p = ho.categorical_from_logits(logits, z["q"][t])
+        assert np.array_equal(s, z["step_sampled"][t])
+        tokens[:, slot] = z["step_sampled"][t]
+
+
+def test_free_running_philox_and_ragged_rows(micro):
+    """Generated noise (shared Philox contract), dropout faithful, ragged T incl. T = 0, shard invariance."""
+    from hudiff_amd import synthetic as S
+    kind = micro["kind"]
+    batch = S.synthetic_batch(kind, 5, seed=11)
+    T = batch["T"].copy()
+    T[1] = 7; T[3] = 0
+    kw = dict(seed=0xDEADBEEFCAFE, dropout="faithful")
+    out = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, row0=100, **kw)
+    want = ho.sample(micro["o1"], batch["tokens"], batch["region"], batch["chain"], batch["order"], T,
+                     seed=0xDEADBEEFCAFE, row0=100, dropout_mode="philox")
+    assert np.array_equal(out, want)
+    assert np.array_equal(out[3], batch["tokens"][3]) and (out[1] == 22).sum() == batch["T"][1] - 7
+    # same global rows computed as two shards give the same tokens
+    chain = batch["chain"]
+    def sub(lo, hi):
+        ch = None if chain is None else np.concatenate([chain[lo:hi], chain[5 + lo:5 + hi]])
+        return micro["m1"].sample(batch["tokens"][lo:hi], batch["region"][lo:hi], ch, batch["order"][lo:hi], T[lo:hi],
+                                  row0=100 + lo, **kw)
+    assert np.array_equal(np.concatenate([sub(0, 2), sub(2, 5)]), out)
+    # eager launches == graph replay
+    assert np.array_equal(micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T,
+                                             row0=100, graph=False, **kw), out)
+
+
+def test_empty_batch_and_errors(micro, hip):
+    from hudiff_amd._lib import HudiffError
+    m = micro["m0"]
+    L = m.max_len
+    empty = m.sample(np.zeros((0, L), np.int32), np.zeros((0, L), np.int32),
+                     np.zeros(0, np.int32) if micro["kind"] == "ab" else None, np.zeros((0, 1), np.int32), np.zeros(0, np.int32))
+    assert empty.shape == (0, L)
+    z = load_golden(f"micro_{micro['kind']}_forward.npz")
+    bad = z["tokens"].copy(); bad[0, 3] = 23
+    with pytest.raises(HudiffError):
+        m(bad, z["region"], chain_or_none(z))
+    bad_r = z["region"].copy(); bad_r[0, 0] = 7
+    with pytest.raises(HudiffError):
+        m(z["tokens"], bad_r, chain_or_none(z))
+    with pytest.raises(AssertionError):
+        m(z["tokens"][:, :-1], z["region"][:, :-1], chain_or_none(z))
+    if micro["kind"] == "ab":
+        with pytest.raises(HudiffError):
+            m(z["tokens"], z["region"], np.array([0, 0, 2, 2, 2, 2]))
+
+
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_production_config_forward_vs_oracle(hip, kind):
+    """Full-width architecture (configs/antibody_train.yml / heavy_train.yml), random weights, small B."""
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    sd = S.random_state_dict(kind, cfg, seed=3)
+    B = 3
+    batch = S.synthetic_batch(kind, B, seed=5)
+    tokens = batch["tokens"].copy()
+    tokens[1] = np.where(tokens[1] == 22, batch["truth"][1], tokens[1])       # one fully unmasked row
+    m = _mk(hip, kind, cfg, sd)
+    try:
+        o_off = ho.OracleNet(kind, dict(cfg, dropout=0.0), sd)
+        got = m(tokens, batch["region"], batch["chain"], dropout="off")
+        want = o_off(tokens, batch["region"], batch["chain"])
+        err = np.abs(got - want).max()
+        assert err < LOGIT_TOL, err
+        o_on = ho.OracleNet(kind, cfg, sd)
+        got = m(tokens, batch["region"], batch["chain"], dropout="faithful", seed=99, row0=3, step=17)
+        want = o_on(tokens, batch["region"], batch["chain"],
+                    dropout=ho.Dropout("philox", seed=99, rows=np.arange(B) + 3, step=17))
+        err = np.abs(got - want).max()
+        assert err < LOGIT_TOL, err
+    finally:
+        m.close()
+
+
+def test_large_batch_properties(hip):
+    """BASELINE-size batch (B = 256, nanobody width): size-independent properties, no oracle.
+    Rows are independent, so (a) duplicated rows with the same global id and noise give identical
+    tokens, (b) a 256-row batch equals the same rows run as a 32-row batch, (c) every masked slot is
+    filled with an id in [0, 21] and unmasked slots are untouched."""
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.NB_CONFIG)
+    sd = S.random_state_dict("nb", cfg, seed=8)
+    m = _mk(hip, "nb", cfg, sd)
+    try:
+        B = 256
+        batch = S.synthetic_batch("nb", B, seed=1)
+        steps = 6                                   # a few steps at full batch size keep the test short
+        T = np.minimum(batch["T"], steps)
+        out = m.sample(batch["tokens"], batch["region"], None, batch["order"], T, seed=4, row0=0)
+        small = m.sample(batch["tokens"][:32], batch["region"][:32], None, batch["order"][:32], T[:32], seed=4, row0=0)
+        assert np.array_equal(out[:32], small)
+        changed = out != batch["tokens"]
+        assert (changed.sum(1) == T).all()
+        assert ((out[changed] >= 0) & (out[changed] <= 21)).all()
+        for b in range(0, B, 37):
+            visited = batch["order"][b, :T[b]]
+            assert set(np.nonzero(changed[b])[0]) == set(visited.tolist())
+    finally:
+        m.close()
