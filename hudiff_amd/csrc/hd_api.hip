@@ -111,6 +111,7 @@ struct HdModel {
     int graph_B = -1; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_steps = 0; bool timed = false;
+    int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
 };
 
 static int dilation_of(const HdConfig& c, int n) {
@@ -225,12 +226,21 @@ extern "C" HdStatus hd_load_tensor(HdModel* m, const char* key, const float* dat
     if (m->finalized) return fail(HD_ERR_STATE, "hd_load_tensor: model already finalized");
     std::string k(key);
     if (k.rfind("module.", 0) == 0) k = k.substr(7);          // antibody_train.py:23-30 strips this prefix
-    if (ends_with(k, ".rope") || k == "pos_encoder.pos_embedding.pe") return HD_OK;   // recomputable buffers
     if (!data) return fail(HD_ERR_INVALID, "hd_load_tensor: null data for %s", key);
+    // Buffers of the checkpoint: kept so the kernels use the reference's own float32
+    // tables bit for bit.  '...rope' is complex64 [L, hd/2] viewed as float32 [L, hd/2, 2]; every layer
+    // holds the same table (cross_attention.py:145-146), so one copy is stored.
+    if (ends_with(k, ".rope")) k = "rope";
     HostTensor t;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(HD_ERR_INVALID, "hd_load_tensor: %s bad shape", key); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
     t.data.assign(data, data + n);
+    if (k == "rope" && m->host.count(k)) {
+        const HostTensor& prev = m->host[k];
+        if (prev.shape != t.shape || memcmp(prev.data.data(), t.data.data(), n * sizeof(float)) != 0)
+            return fail(HD_ERR_UNSUPPORTED, "hd_load_tensor: %s differs from the other layers' RoPE table", key);
+        return HD_OK;
+    }
     m->host[k] = std::move(t);
     return HD_OK;
 }
@@ -375,14 +385,17 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     r_l0g = pk.add(ld.vec("region_encoder.region_layer1.0.weight", re)); r_l0b = pk.add(ld.vec("region_encoder.region_layer1.0.bias", re));
     r_w = pk.add(ld.lin_t("region_encoder.region_layer1.2.conv.weight", d, re, true)); r_b = pk.add(ld.vec("region_encoder.region_layer1.2.conv.bias", d));
     r_l1g = pk.add(ld.vec("region_encoder.region_layer1.3.weight", d)); r_l1b = pk.add(ld.vec("region_encoder.region_layer1.3.bias", d));
-    {   // sinusoid table, float32 arithmetic as torch builds the 'pe' buffer (model/encoder/model.py:70-78)
+    if (m->host.count("pos_encoder.pos_embedding.pe")) {
+        auto t = ld.get("pos_encoder.pos_embedding.pe", {L, 1, d});
+        r_pe = pk.add(t ? t->data : std::vector<float>((size_t)L * d));
+    } else {   // sinusoid table (model/encoder/model.py:70-78), evaluated in double and rounded once
         std::vector<float> pe((size_t)L * d);
         for (int i = 0; i < d; i += 2) {
-            float div = expf((float)i * (float)(-log(10000.0) / d));
+            double div = exp((double)i * (-log(10000.0) / d));
             for (int l = 0; l < L; ++l) {
-                float ang = (float)l * div;
-                pe[(size_t)l * d + i] = sinf(ang);
-                pe[(size_t)l * d + i + 1] = cosf(ang);
+                double ang = (double)l * div;
+                pe[(size_t)l * d + i] = (float)sin(ang);
+                pe[(size_t)l * d + i + 1] = (float)cos(ang);
             }
         }
         r_pe = pk.add(pe);
@@ -405,12 +418,17 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     size_t o_cos, o_sin;
     {
         std::vector<float> cs((size_t)L * 32), sn((size_t)L * 32);
-        for (int k = 0; k < 32; ++k) {
-            float freq = 1.0f / powf(10000.0f, (float)(2 * k) / (float)ATT_HD);
-            for (int t = 0; t < L; ++t) {
-                float ang = (float)t * freq;
-                cs[(size_t)t * 32 + k] = cosf(ang);
-                sn[(size_t)t * 32 + k] = sinf(ang);
+        if (m->host.count("rope")) {
+            auto t = ld.get("rope", {L, ATT_HD / 2, 2});
+            if (t) for (size_t i = 0; i < (size_t)L * 32; ++i) { cs[i] = t->data[2 * i]; sn[i] = t->data[2 * i + 1]; }
+        } else {
+            for (int k = 0; k < 32; ++k) {
+                double freq = 1.0 / pow(10000.0, (double)(2 * k) / (double)ATT_HD);
+                for (int t = 0; t < L; ++t) {
+                    double ang = (double)t * freq;
+                    cs[(size_t)t * 32 + k] = (float)cos(ang);
+                    sn[(size_t)t * 32 + k] = (float)sin(ang);
+                }
             }
         }
         o_cos = pk.add(cs); o_sin = pk.add(sn);
@@ -634,12 +652,14 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
                       last ? ws.EXTRA : nullptr, d);
     }
+    if (m->debug_stop_after == 1) return HD_OK;
     for (int n = 0; n < c.dual_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
+        if (m->debug_stop_after == 2 + n) return HD_OK;
         const AttBlockW& w = m->att[n];
         // at = x + A1(x)
         attention_layer(m, sg, w.a1, ws.Y, false, nullptr, nullptr, ws.Y, ws.AT);
@@ -883,5 +903,38 @@ extern "C" HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps) {
     HIP_TRY(hipEventSynchronize(m->ev1));
     HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
     if (steps) *steps = m->last_steps;
+    return HD_OK;
+}
+
+// ---- debugging aids (used by tests to localise a parity failure; not part of the product path) ---------
+extern "C" HdStatus hd_debug_stop_after(HdModel* m, int32_t stage) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_debug_stop_after: null model");
+    m->debug_stop_after = stage;   // 1: after the token encoder (+static add), 2+n: before attention block n
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats) {
+    if (!m || !name || !out) return fail(HD_ERR_INVALID, "hd_debug_read: null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    const Workspace& ws = m->ws;
+    const std::string k(name);
+    const float* src = nullptr;
+    int width = 0;
+    if (k == "FEAT") { src = ws.FEAT; width = m->D; }
+    else if (k == "Y") { src = ws.Y; width = m->D; }
+    else if (k == "X") { src = ws.X; width = m->d; }
+    else if (k == "POS") { src = ws.POS; width = m->d; }
+    else if (k == "EXTRA") { src = ws.EXTRA; width = m->d; }
+    else if (k == "AT") { src = ws.AT; width = m->D; }
+    else return fail(HD_ERR_INVALID, "hd_debug_read: unknown buffer %s", name);
+    if (B > ws.capB || n_floats != (int64_t)B * m->L * width) return fail(HD_ERR_INVALID, "hd_debug_read: size mismatch");
+    // rows are segment-major on the device; return them as [B, L, width]
+    std::vector<float> tmp((size_t)n_floats);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    const Segs sg = make_segs(m, B);
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < m->L; ++l)
+            memcpy(out + ((size_t)b * m->L + l) * width, tmp.data() + (size_t)sg.row(b, l) * width, sizeof(float) * width);
     return HD_OK;
 }

@@ -37,6 +37,23 @@ def _to_numpy(x):
     return np.asarray(x), False
 
 
+def _sinusoid_pe(max_len, d_model):
+    f32 = np.float32
+    position = np.arange(max_len, dtype=f32)[:, None]
+    div = np.exp(np.arange(0, d_model, 2).astype(f32) * f32(-np.log(10000.0) / d_model)).astype(f32)
+    ang = (position * div).astype(f32)
+    pe = np.zeros((max_len, d_model), dtype=f32)
+    pe[:, 0::2], pe[:, 1::2] = np.sin(ang), np.cos(ang)
+    return pe
+
+
+def _rope_table(head_dim, length, theta=10000.0):
+    f32 = np.float32
+    freqs = (f32(1.0) / (f32(theta) ** (np.arange(0, head_dim, 2)[: head_dim // 2].astype(f32) / f32(head_dim)))).astype(f32)
+    ang = np.outer(np.arange(length, dtype=f32), freqs).astype(f32)
+    return np.stack([np.cos(ang), np.sin(ang)], axis=-1).astype(f32)
+
+
 class _Denoiser:
     kind = None            # 'ab' | 'nb'
 
@@ -87,18 +104,28 @@ class _Denoiser:
             raise RuntimeError("weights already loaded into this handle")
         if not strict:
             raise NotImplementedError("strict=False is not supported")
+        keys = set()
         for key, val in state_dict.items():
-            if hasattr(val, "is_complex") and val.is_complex():       # '...rope' buffers: recomputed
-                continue
             arr, _ = _to_numpy(val)
-            if np.iscomplexobj(arr):
-                continue
-            arr = np.ascontiguousarray(arr, dtype=np.float32)
-            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
-            L.check(self._lib.hd_load_tensor(self._h, key.encode(), L.ptr(arr, C.c_float), shape, arr.ndim))
+            if np.iscomplexobj(arr):             # '...rope' complex64 [L, hd/2] -> float32 [L, hd/2, 2]
+                arr = np.stack([arr.real, arr.imag], axis=-1)
+            self._load(key, arr)
+            keys.add(key[7:] if key.startswith("module.") else key)
+        # Buffers a stripped state_dict may lack: built the way torch builds them (float32 arithmetic),
+        # model/encoder/model.py:70-78 and model/encoder/cross_attention.py:35-56.
+        if "pos_encoder.pos_embedding.pe" not in keys:
+            self._load("pos_encoder.pos_embedding.pe", _sinusoid_pe(self.max_len, self.config["d_model"])[:, None, :])
+        if not any(k.endswith(".rope") for k in keys):
+            self._load("self_at.layers.0.attn_hl.rope",
+                       _rope_table(self.config["att_model"] // self.config["nhead"], self.max_len))
         L.check(self._lib.hd_finalize(self._h))
         self._loaded = True
         return self
+
+    def _load(self, key, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+        L.check(self._lib.hd_load_tensor(self._h, key.encode(), L.ptr(arr, C.c_float), shape, arr.ndim))
 
     def eval(self):
         return self
@@ -213,6 +240,15 @@ class _Denoiser:
         ms, steps = C.c_float(), C.c_int32()
         L.check(self._lib.hd_last_run_ms(self._h, C.byref(ms), C.byref(steps)))
         return float(ms.value), int(steps.value)
+
+    def debug_stop_after(self, stage):
+        L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
+
+    def debug_read(self, name, B):
+        width = {"FEAT": "sum_d_model", "Y": "sum_d_model", "AT": "sum_d_model"}.get(name, "d_model")
+        out = np.empty((B, self.max_len, self.config[width]), dtype=np.float32)
+        L.check(self._lib.hd_debug_read(self._h, name.encode(), B, L.ptr(out, C.c_float), out.size))
+        return out
 
     def flops_per_row_forward(self):
         return float(self._lib.hd_flops_per_row_forward(C.byref(self._cfg)))

@@ -78,7 +78,9 @@ def state_dict_shapes(kind: str, cfg: dict) -> dict:
 
 def random_state_dict(kind: str, cfg: dict, seed: int = 0) -> dict:
     """Seeded float32 weights: matrices ~ N(0, 1/fan_in), LayerNorm gamma ~ 1 + 0.1 N, biases / beta ~ 0.1 N,
-    embeddings ~ N(0, 1).  (Scaled so activations stay O(1) through all 100+ layers.)"""
+    embeddings ~ N(0, 1); the last projection of every residual branch (ByteNet sequence2.2, attention
+    out_put, ff_hl.2) is scaled by 0.1 so that the residual stream stays O(1) through all 100+ layers even
+    with the x2 inference-time dropout scaling -- as it does in a trained network."""
     rng = np.random.default_rng(seed)
     out = {}
     for key, shape in state_dict_shapes(kind, cfg).items():
@@ -90,6 +92,8 @@ def random_state_dict(kind: str, cfg: dict, seed: int = 0) -> dict:
         else:
             fan_in = int(np.prod(shape[1:]))
             v = rng.standard_normal(shape) / np.sqrt(fan_in)
+            if key.endswith(("sequence2.2.conv.weight", "out_put.weight", "ff_hl.2.weight")):
+                v *= 0.1
         out[key] = v.astype(np.float32)
     return out
 

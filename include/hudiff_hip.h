@@ -103,8 +103,9 @@ typedef struct HdModel HdModel;
 int hd_device_count(void);
 HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out);
 /* One call per state_dict entry, `key` = the reference's own key, data = float32 in
- * the torch layout ([out,in] Linear, [out,in,k] Conv1d).  Recomputable buffers ('...rope',
- * 'pos_encoder.pos_embedding.pe') are accepted and ignored.  Unknown keys -> HD_ERR_INVALID (strict). */
+ * the torch layout ([out,in] Linear, [out,in,k] Conv1d).  The checkpoint's buffers are used when given:
+ * 'pos_encoder.pos_embedding.pe' [L,1,d] and '...rope' (complex64 [L,32] passed as float32 [L,32,2],
+ * identical in every layer); when absent they are recomputed.  Unknown keys -> HD_ERR_INVALID (strict). */
 HdStatus hd_load_tensor(HdModel* m, const char* key, const float* data, const int64_t* shape, int32_t ndim);
 /* Checks every required key was loaded with the right shape, re-lays weights for the kernels and uploads. */
 HdStatus hd_finalize(HdModel* m);
@@ -149,6 +150,13 @@ HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps);
 double hd_flops_per_row_forward(const HdConfig* cfg);
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
+
+/* ---- debugging aids (tests only) -----------------------------------------------------------------
+ * hd_debug_stop_after: make hd_forward return after a stage (0 = off, 1 = token encoder, 2+n = before
+ * attention block n); hd_debug_read copies an activation buffer ("X","FEAT","Y","POS","EXTRA","AT") of
+ * the last call back as [B, L, width]. */
+HdStatus hd_debug_stop_after(HdModel* m, int32_t stage);
+HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats);
 
 #ifdef __cplusplus
 }

@@ -123,18 +123,19 @@ def philox_exp_noise(seed: int, rows: np.ndarray, step: int) -> np.ndarray:
 # Elementary ops (float32 throughout)
 # --------------------------------------------------------------------------------------
 def layer_norm(x, w, b, eps=1e-5):
-    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=x.dtype)
     xc = x - mu
-    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
-    return (xc / np.sqrt(var + F32(eps))) * w + b
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=x.dtype)
+    return (xc / np.sqrt(var + x.dtype.type(eps))) * w + b
 
 
 def gelu(x):
-    return (F32(0.5) * x * (F32(1.0) + _erf(x * F32(1.0 / math.sqrt(2.0))))).astype(F32)
+    t = x.dtype.type
+    return (t(0.5) * x * (t(1.0) + _erf(x * t(1.0 / math.sqrt(2.0))))).astype(x.dtype)
 
 
 def relu(x):
-    return np.maximum(x, F32(0.0))
+    return np.maximum(x, x.dtype.type(0.0))
 
 
 ACT = {"gelu": gelu, "relu": relu}
@@ -151,7 +152,7 @@ def dilated_conv(x, w, b, dilation):
     B, Lc, _ = x.shape
     K = w.shape[2]
     half = (K - 1) // 2
-    out = np.zeros((B, Lc, w.shape[0]), dtype=F32)
+    out = np.zeros((B, Lc, w.shape[0]), dtype=x.dtype)
     for tap in range(K):
         s = (tap - half) * dilation
         lo, hi = max(0, -s), min(Lc, Lc - s)
@@ -230,7 +231,7 @@ class Dropout:
 def apply_dropout(x, keep, p):
     if keep is None:
         return x
-    return x * (keep.astype(F32) * F32(1.0 / (1.0 - p)))
+    return x * (keep.astype(x.dtype) * x.dtype.type(1.0 / (1.0 - p)))
 
 
 # --------------------------------------------------------------------------------------
@@ -242,12 +243,15 @@ class OracleNet:
     ``sd`` maps the reference's state_dict keys to numpy arrays.
     """
 
-    def __init__(self, kind: str, cfg: dict, sd: Dict[str, np.ndarray]):
+    def __init__(self, kind: str, cfg: dict, sd: Dict[str, np.ndarray], dtype=F32):
+        """dtype=np.float64 evaluates the same float32 weights in double precision (used by tests to
+        separate float32 round-off of the path itself from implementation differences)."""
         assert kind in ("ab", "nb")
         self.kind = kind
         self.cfg = dict(cfg)
+        self.dt = np.dtype(dtype).type
         self.sd = {k: np.asarray(v) for k, v in sd.items() if not np.iscomplexobj(v)}
-        self.sd = {k: v.astype(F32) for k, v in self.sd.items()}
+        self.sd = {k: v.astype(F32).astype(self.dt) for k, v in self.sd.items()}
         c = self.cfg
         self.L = int(c["max_len"])
         self.d = int(c["d_model"])
@@ -266,8 +270,8 @@ class OracleNet:
             assert self.L == AB_H_LEN + AB_L_LEN
         self.enc_dil = dilations(int(c["n_encoder_layers"]), int(c["r"]))
         self.conv_dil = dilations(int(c["dual_layers"]), int(c["r"]))
-        self.pe = sinusoid_pe(self.L, int(c["n_pos_model"]))
-        self.cos, self.sin = rope_table(self.att // self.nhead, self.L)
+        self.pe = sinusoid_pe(self.L, int(c["n_pos_model"])).astype(self.dt)
+        self.cos, self.sin = (t.astype(self.dt) for t in rope_table(self.att // self.nhead, self.L))
         self.trace: Optional[dict] = None     # set to {} to record intermediate activations
 
     # -- helpers -------------------------------------------------------------------
@@ -327,7 +331,7 @@ class OracleNet:
             assert h_rows.shape[0] == B and l_rows.shape[0] == B
             chn = np.concatenate([np.repeat(h_rows[:, None, :], AB_H_LEN, axis=1),
                                   np.repeat(l_rows[:, None, :], AB_L_LEN, axis=1)], axis=1)
-        return pos.astype(F32), (None if chn is None else chn.astype(F32))
+        return pos.astype(self.dt), (None if chn is None else chn.astype(self.dt))
 
     def _attn(self, x, pre):
         """AttLayer.forward (cross_attention.py:149-173), context=None."""
@@ -339,10 +343,10 @@ class OracleNet:
         v = linear(x, s[pre + "value.weight"], s[pre + "value.bias"]).reshape(B, L, H, hd)
         q, k = apply_rope(q, self.cos, self.sin), apply_rope(k, self.cos, self.sin)
         q, k, v = (t.transpose(0, 2, 1, 3) for t in (q, k, v))
-        w = (q @ k.transpose(0, 1, 3, 2)) / F32(math.sqrt(self.att / self.nhead))
+        w = (q @ k.transpose(0, 1, 3, 2)) / self.dt(math.sqrt(self.att / self.nhead))
         w = w - w.max(axis=-1, keepdims=True)
         w = np.exp(w)
-        w = w / w.sum(axis=-1, keepdims=True, dtype=F32)
+        w = w / w.sum(axis=-1, keepdims=True, dtype=self.dt)
         o = (w @ v).transpose(0, 2, 1, 3).reshape(B, L, H * hd)
         return linear(o, s[pre + "out_put.weight"], s[pre + "out_put.bias"])
 
@@ -381,14 +385,14 @@ class OracleNet:
             feat = np.concatenate([emb, pos], axis=-1)
         self._rec("feature", feat)
         p_conv = 0.5 if self.p_enc > 0.0 else 0.0      # F.dropout(x) default p, gated by cfg.dropout > 0
-        h = self._conv_stack(feat.astype(F32), self.conv_prefix, self.conv_dil, self.conv_act, p_conv, "conv", drop)
+        h = self._conv_stack(feat.astype(self.dt), self.conv_prefix, self.conv_dil, self.conv_act, p_conv, "conv", drop)
         self._rec("conv", h)
         for n in range(int(self.cfg["cs_layers"])):
             h = self._self_att_block(h, n)
             self._rec(f"att{n}", h)
         h = layer_norm(h, s["last_norm.weight"], s["last_norm.bias"])
         logits = linear(h, s["decoder.weight"], s["decoder.bias"])
-        return logits.astype(F32)
+        return logits.astype(self.dt)
 
     __call__ = forward
 
