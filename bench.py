@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- humanized sequences / second (full T-step sample), the BASELINE.json metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete T-step humanization sample of one batch of B = 256 independent rows per GPU
+(BASELINE.json configs[1]: HuDiff-Ab, HuAb348-shaped inputs, batch 256, 1 x MI355X): ~155 denoiser
+forwards of the 39.8 M-parameter AntiTFNet over 291 slots + the exponential-race resampling, with
+inference-time dropout as the reference runs it.  Inputs are synthetic (no ANARCI, no
+released checkpoint offline): HuAb348-shaped pre-slotted rows and seeded random weights of the exact
+production architecture.  Rows shard across GPUs with no data-path collective; one RCCL gather of the
+final int32 tokens ends the job (weak scaling: 256 rows per GPU).
+
+Timed region: inputs already resident in HBM (hd_sample_begin uploaded them); K x [restore tokens
+device-side, re-key noise, run all T steps]; bracketed by barrier + device synchronise on both sides,
+max over ranks.  One JSON line is printed by rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
+    ap.add_argument("--kind", choices=["ab", "nb"], default="ab")
+    ap.add_argument("--mode", default=None, help="ab: finetune|pretrain, nb: plain|inpaint")
+    ap.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
+    ap.add_argument("--max-t", type=int, default=0, help="truncate every row to this many denoiser steps "
+                    "(profiling aid; the JSON line is then marked truncated and is NOT the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T):
+    """The oracle (numpy port of the reference algorithm) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hudiff_oracle as ho
+    from hudiff_amd import synthetic as S
+    batch = S.synthetic_batch(kind, rows, seed=2023, mode=mode)
+    net = ho.OracleNet(kind, cfg, sd)
+    T = np.minimum(batch["T"], steps + 1)
+    ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, 1),
+              seed=1, dropout_mode="philox")                                   # warm-up (BLAS threads, caches)
+    t0 = time.perf_counter()
+    ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, steps),
+              seed=1, dropout_mode="philox")
+    dt = time.perf_counter() - t0
+    per_step = dt / steps
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": rows / (per_step * mean_T), "unit": "sequences/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle/hudiff_oracle.py (numpy+OpenBLAS), {rows} rows x {steps} denoiser steps with philox "
+                      f"dropout in {dt:.1f} s, extrapolated to the mean T = {mean_T:.1f} steps per sequence"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    n_gpus = world
+
+    import hudiff_amd
+    from hudiff_amd import synthetic as S
+
+    kind = args.kind
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    mode = args.mode or ("finetune" if kind == "ab" else "plain")
+    sd = S.random_state_dict(kind, cfg, seed=0)
+    B = args.batch
+    batch = S.synthetic_batch(kind, B, seed=2023, mode=mode, row0=rank * B)
+    T = batch["T"].copy()
+    if args.max_t > 0:
+        T = np.minimum(T, args.max_t)
+    Tmax = int(T.max())
+
+    model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
+    model.load_state_dict(sd)
+    flops_row = model.flops_per_row_forward()
+
+    def barrier():
+        model.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    t_up0 = time.perf_counter()
+    model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
+                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph)
+    upload_s = time.perf_counter() - t_up0
+    gpu_ms = 0.0
+
+    def one_sample(i, timed):
+        nonlocal gpu_ms
+        model.sample_restart(2023 + 7919 * i)
+        model.sample_run(0, Tmax)
+        if timed:
+            model.sync()
+            gpu_ms += model.last_run_ms()[0]
+
+    for i in range(args.warmup):
+        one_sample(-1 - i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_sample(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tokens = model.sample_end()
+
+    # ---- the single collective of the job: gather the final tokens on rank 0 (RCCL over xGMI) ----------
+    gathered = [tokens]
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(tokens).cuda()
+        outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, outs, dst=0)
+        if rank == 0:
+            gathered = [o.cpu().numpy() for o in outs]
+        el = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms = float(el[0]), float(el[1])
+
+    if rank == 0:
+        all_tokens = np.concatenate(gathered)
+        filled = bool(((all_tokens >= 0) & (all_tokens <= 22)).all())
+        if args.max_t == 0:
+            assert not (all_tokens == 22).any(), "masked slots left after a full sample"
+        seqs = n_gpus * B * args.steps
+        value = seqs / elapsed
+        useful_flops = float(T.sum()) * flops_row * args.steps            # per GPU, algorithmic
+        executed_flops = float(B * Tmax) * flops_row * args.steps          # every row is computed every step
+        achieved = useful_flops / (gpu_ms * 1e-3) / 1e12
+        out = {
+            "metric": "humanized sequences/sec (full T-step sample)",
+            "value": round(value, 4), "unit": "sequences/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("HuDiff-Ab AntiTFNet (39.8M params, L=291), HuAb348-shaped synthetic rows, "
+                                    if kind == "ab" else "HuDiff-Nb NanoAntiTFNet (17.5M params, L=152), VHH-shaped synthetic rows, ")
+                       + f"{mode} mask, batch {B}/GPU, full T-step sample (mean T {float(batch['T'].mean()):.1f}), "
+                         f"dropout {args.dropout}",
+                       "rows_per_gpu": B, "global_rows": n_gpus * B, "denoiser_steps_per_sample": Tmax,
+                       "parallelism": f"rows sharded x{n_gpus}, one RCCL gather of int32 tokens"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "launch": "one denoiser step = one replay of the captured hipGraph (all kernels of a forward "
+                                   "+ sampling), HIP events on the library's stream",
+                         "flops_per_launch": B * flops_row, "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
+                         "executed_tflops": round(executed_flops / (gpu_ms * 1e-3) / 1e12, 3)},
+            "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
+        }
+        if args.max_t > 0:
+            out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(kind, cfg, sd, mode, args.cpu_rows, args.cpu_steps, float(batch["T"].mean()))
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

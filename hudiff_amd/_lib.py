@@ -21,7 +21,7 @@ HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_D
 
 EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",
-    "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_end", "hd_sync",
+    "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
     "hd_last_run_ms", "hd_flops_per_row_forward", "hd_device_info", "hd_debug_stop_after", "hd_debug_read",
 ]
 
@@ -69,6 +69,7 @@ def load():
     lib.hd_sample.argtypes = [vp, i32p] + sample_args
     lib.hd_sample_begin.argtypes = [vp, i32p] + sample_args
     lib.hd_sample_run.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.hd_sample_restart.argtypes = [vp, C.c_uint64]
     lib.hd_sample_end.argtypes = [vp, i32p]
     lib.hd_sync.argtypes = [vp]
     lib.hd_last_run_ms.argtypes = [vp, f32p, i32p]

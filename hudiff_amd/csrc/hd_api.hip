@@ -72,7 +72,7 @@ struct Workspace {
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float2* ST = nullptr;
     float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
-    int32_t *tokens = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
+    int32_t *tokens = nullptr, *tokens0 = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
     int capT = 0;
     float* qnoise = nullptr; size_t qnoise_cap = 0;
     uint8_t *enc_masks = nullptr, *conv_masks = nullptr; size_t enc_cap = 0, conv_cap = 0;
@@ -104,6 +104,7 @@ struct HdModel {
     // sampling session
     bool in_session = false;
     int sB = 0, sTmax = 0;
+    uint64_t s_row0 = 0;
     uint32_t sflags = 0;
     bool s_has_q = false;
     hipGraph_t graph = nullptr;
@@ -505,7 +506,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
     HD_TRY(dalloc(ws, &ws.ST, M));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
-    HD_TRY(dalloc(ws, &ws.tokens, M)); HD_TRY(dalloc(ws, &ws.region, M)); HD_TRY(dalloc(ws, &ws.chain, (size_t)2 * B));
+    HD_TRY(dalloc(ws, &ws.tokens, M)); HD_TRY(dalloc(ws, &ws.tokens0, M)); HD_TRY(dalloc(ws, &ws.region, M)); HD_TRY(dalloc(ws, &ws.chain, (size_t)2 * B));
     HD_TRY(dalloc(ws, &ws.T, (size_t)B));
     ws.capB = B;
     return HD_OK;
@@ -820,10 +821,21 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
         HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->stream));
         HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->stream));
     }
+    HIP_TRY(hipMemcpyAsync(ws.tokens0, ws.tokens, (size_t)B * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
     HD_TRY(set_run_state(m, seed, row0, 0));
     HD_TRY(static_branch(m, sg));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    m->s_row0 = row0;
     m->in_session = true;
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_restart(HdModel* m, uint64_t seed) {
+    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_restart: no open session");
+    if (m->sB == 0) return HD_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(m->ws.tokens, m->ws.tokens0, (size_t)m->sB * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+    HD_TRY(set_run_state(m, seed, m->s_row0, 0));
     return HD_OK;
 }
 

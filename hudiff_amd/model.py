@@ -228,6 +228,9 @@ class _Denoiser:
     def sample_run(self, t0, t1):
         L.check(self._lib.hd_sample_run(self._h, int(t0), int(t1)))
 
+    def sample_restart(self, seed):
+        L.check(self._lib.hd_sample_restart(self._h, int(seed)))
+
     def sync(self):
         L.check(self._lib.hd_sync(self._h))
 

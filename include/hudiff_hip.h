@@ -139,6 +139,9 @@ HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int32_t* regio
                          uint64_t seed, uint64_t row0, const float* q_noise,
                          const uint8_t* enc_masks, const uint8_t* conv_masks);
 HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1);
+/* Restores the tokens to their state at hd_sample_begin (device-to-device) and re-keys the noise with a new
+ * seed, so that the same resident batch can be sampled again (independent replicas; bench.py). */
+HdStatus hd_sample_restart(HdModel* m, uint64_t seed);
 HdStatus hd_sample_end(HdModel* m, int32_t* tokens);
 HdStatus hd_sync(HdModel* m);
 

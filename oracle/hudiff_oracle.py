@@ -152,14 +152,27 @@ def dilated_conv(x, w, b, dilation):
     B, Lc, _ = x.shape
     K = w.shape[2]
     half = (K - 1) // 2
+    wt = _tap_major(w)                                  # [K, Cin, Cout] contiguous (BLAS-friendly)
     out = np.zeros((B, Lc, w.shape[0]), dtype=x.dtype)
     for tap in range(K):
         s = (tap - half) * dilation
         lo, hi = max(0, -s), min(Lc, Lc - s)
         if hi <= lo:
             continue
-        out[:, lo:hi, :] += x[:, lo + s:hi + s, :] @ w[:, :, tap].T
+        out[:, lo:hi, :] += np.ascontiguousarray(x[:, lo + s:hi + s, :]) @ wt[tap]
     return out + b
+
+
+_TAP_CACHE: dict = {}
+
+
+def _tap_major(w):
+    key = id(w)
+    hit = _TAP_CACHE.get(key)
+    if hit is None or hit[0] is not w:
+        hit = (w, np.ascontiguousarray(w.transpose(2, 1, 0)))
+        _TAP_CACHE[key] = hit
+    return hit[1]
 
 
 def sinusoid_pe(max_len, d_model):
