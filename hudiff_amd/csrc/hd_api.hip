@@ -534,17 +534,31 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     Segs run = p.sg;
     if (!per_seg) {           // weights shared by all rows: treat the whole batch as one segment
         run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0;
-        // NB: with nseg = 1 rows are contiguous [0, B*L); slot bookkeeping is not needed by shared-weight GEMMs
     }
     GemmP q = p;
     q.sg = run;
     const int rows0 = run.B * run.len[0];
     const int rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
     q.tiles0 = (rows0 + BM - 1) / BM;
-    const int tiles = q.tiles0 + (rows1 + BM - 1) / BM;
-    dim3 grid(tiles, (q.N + BN - 1) / BN);
-    if (conv) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, q);
-    else hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, q);
+    q.tiles_m = q.tiles0 + (rows1 + BM - 1) / BM;
+    q.tiles_n = (q.N + BN - 1) / BN;
+    dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
+    const int pro = q.stats ? 1 + q.pro_act : 0;      // 0 none, 1 LN, 2 LN+ReLU, 3 LN+GELU
+#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO>), grid, blk, 0, st, q)
+    if (!conv) {
+        switch (pro) {
+            case 0: HD_LAUNCH(false, 0); break;
+            case 1: HD_LAUNCH(false, 1); break;
+            case 2: HD_LAUNCH(false, 2); break;
+            default: HD_LAUNCH(false, 3); break;
+        }
+    } else {
+        switch (pro) {
+            case 2: HD_LAUNCH(true, 2); break;
+            default: HD_LAUNCH(true, 3); break;      // the ByteNet convolution always has LN + activation
+        }
+    }
+#undef HD_LAUNCH
 }
 
 static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st) {

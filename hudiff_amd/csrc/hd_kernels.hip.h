@@ -114,16 +114,30 @@ struct GemmP {
     // geometry
     Segs sg;
     int tiles0;                       // number of M tiles of segment 0
+    int tiles_m, tiles_n;             // total M tiles (both segments), N tiles
 };
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+// PRO: A-operand prologue, fixed at compile time so the K loop is branch-free:
+//   0 = none, 1 = LayerNorm, 2 = LayerNorm + ReLU, 3 = LayerNorm + GELU
+template <int PRO>
+__device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g, float b) {
+    if (PRO == 0) return x;
+    float v = (x - mean) * rstd * g + b;
+    if (PRO == 2) v = fmaxf(v, 0.0f);
+    if (PRO == 3) v = gelu_f(v);
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO>
 __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
     constexpr int BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AIT = (BM * 4 + 255) / 256, BIT = (BN * 4 + 255) / 256;
+    constexpr bool A_FULL = (BM * 4) % 256 == 0;      // every thread stages A
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+    static_assert((BN * 4) % 256 == 0, "every thread stages W");
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
@@ -131,93 +145,108 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    int bx = blockIdx.x, seg = 0;
+    // Block -> (M tile, N tile).  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, an
+    // observed property used for speed only), each with a private 4 MiB L2.  All N tiles of one M tile are
+    // given to the SAME XCD on consecutive slots, so the fp32 A panel (BM x K x 4 B) is fetched from HBM once
+    // and re-read from that L2 by the other N tiles instead of streaming from HBM N/BN times.
+    int bx, by, seg = 0;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        by = slot % p.tiles_n;
+        bx = (slot / p.tiles_n) * 8 + xcd;
+        if (bx >= p.tiles_m) return;
+    }
     if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
     const int Lc = p.sg.len[seg];
     const int seg_rows = p.sg.B * Lc;
     const int rbase = p.sg.base[seg];
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const float* __restrict__ W = p.W + (long)seg * p.w_stride;
-    const float* __restrict__ gamma = p.gamma ? p.gamma + seg * p.k_stride : nullptr;
-    const float* __restrict__ beta = p.beta ? p.beta + seg * p.k_stride : nullptr;
+    const float* __restrict__ gamma = PRO ? p.gamma + seg * p.k_stride : nullptr;
+    const float* __restrict__ beta = PRO ? p.beta + seg * p.k_stride : nullptr;
     const int N = p.N, Kc = p.Kc;
-    const bool has_ln = p.stats != nullptr;
     const int nkt_tap = (Kc + BK - 1) / BK;
     const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
 
-    // per-thread A rows (fixed over the K loop)
-    int a_r[AIT], a_kq[AIT], a_pos[AIT];
+    // per-thread staging coordinates (fixed over the K loop)
+    const int a_kq = tid & 3;                         // k quad within the 16-wide k tile (same for every A row)
+    int a_r[AIT], a_pos[AIT];
     bool a_ok[AIT];
+    long a_row[AIT];
+    float2 a_st[AIT];
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
-        int idx = tid + 256 * i;
-        a_r[i] = idx >> 2; a_kq[i] = idx & 3;
-        int lrow = m0 + a_r[i];
-        a_ok[i] = (idx < BM * 4) && (lrow < seg_rows);
+        const int idx = tid + 256 * i;
+        a_r[i] = idx >> 2;
+        const int lrow = m0 + a_r[i];
+        a_ok[i] = (A_FULL || idx < BM * 4) && (lrow < seg_rows);
         a_pos[i] = CONV ? (lrow % Lc) : 0;
+        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;  // clamped: always a readable row
+        a_st[i] = make_float2(0.f, 0.f);
+        if (PRO && !CONV) a_st[i] = p.stats[a_row[i]];
     }
+    const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);          // + (256 / (BN/4)) * i rows per iteration
+    constexpr int B_KSTEP = 256 / (BN / 4);
+    const int b_col = n0 + 4 * b_nq;
+    const bool b_ok = b_col < N;
+    const int b_colc = b_ok ? b_col : 0;
 
-    f32x4 ra[AIT], rg[AIT], rb[AIT], rw[BIT];
+    f32x4 ra[AIT], rw[BIT], rg, rb;
     float2 rst[AIT];
     bool rav[AIT];
 
+    // Loads are unconditional (addresses clamped to something readable) and invalid lanes are zeroed at
+    // commit time: no divergent branch sits between a load and its use, so hipcc can issue the whole
+    // k-tile's loads back to back and overlap them with the MFMAs of the current tile.
     auto fetch = [&](int kt) {
         const int tap = CONV ? kt / nkt_tap : 0;
         const int kk0 = (CONV ? kt % nkt_tap : kt) * BK;
         const int shift = CONV ? (tap - half) * p.dil : 0;
+        const int col = kk0 + 4 * a_kq;
+        const bool kv = col < Kc;
+        const int colc = kv ? col : 0;
+        if (PRO) {
+            rg = *reinterpret_cast<const f32x4*>(gamma + colc);
+            rb = *reinterpret_cast<const f32x4*>(beta + colc);
+        }
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int col = kk0 + 4 * a_kq[i];
-            bool v = a_ok[i] && col < Kc;
-            if (CONV) { int sp = a_pos[i] + shift; v = v && sp >= 0 && sp < Lc; }
-            rav[i] = v;
-            const long srow = (long)rbase + m0 + a_r[i] + shift;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = z; rg[i] = z; rb[i] = z; rst[i] = make_float2(0.f, 0.f);
-            if (v) {
-                ra[i] = *reinterpret_cast<const f32x4*>(p.A + srow * p.lda + col);
-                if (has_ln) {
-                    rst[i] = p.stats[srow];
-                    rg[i] = *reinterpret_cast<const f32x4*>(gamma + col);
-                    rb[i] = *reinterpret_cast<const f32x4*>(beta + col);
-                }
+            bool v = a_ok[i] && kv;
+            long srow = a_row[i];
+            if (CONV) {
+                const int sp = a_pos[i] + shift;
+                v = v && sp >= 0 && sp < Lc;
+                srow = v ? srow + shift : 0;
             }
+            rav[i] = v;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + srow * p.lda + colc);
+            if (PRO && CONV) rst[i] = p.stats[srow];
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            int idx = tid + 256 * i;
-            int kr = idx / (BN / 4), nq = idx % (BN / 4);
-            int ncol = n0 + 4 * nq;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rw[i] = z;
-            if (idx < BN * 4 && kk0 + kr < Kc && ncol < N)
-                rw[i] = *reinterpret_cast<const f32x4*>(W + (long)(tap * Kc + kk0 + kr) * N + ncol);
+            const int kr = b_kr + B_KSTEP * i;
+            const bool v = b_ok && (kk0 + kr < Kc);
+            const long wrow = v ? (long)(tap * Kc + kk0 + kr) : 0;
+            rw[i] = *reinterpret_cast<const f32x4*>(W + wrow * N + b_colc);
+            if (!v) { rw[i][0] = 0.f; rw[i][1] = 0.f; rw[i][2] = 0.f; rw[i][3] = 0.f; }
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            if (tid + 256 * i < BM * 4) {
-                f32x4 v = ra[i];
-                if (has_ln) {
+            if (A_FULL || tid + 256 * i < BM * 4) {
+                const float2 st = CONV ? rst[i] : a_st[i];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        v[c] = act_f((v[c] - rst[i].x) * rst[i].y * rg[i][c] + rb[i][c], p.pro_act);
-                    if (!rav[i]) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                for (int c = 0; c < 4; ++c) {
+                    float v = pro_f<PRO>(ra[i][c], st.x, st.y, rg[c], rb[c]);
+                    As[buf][4 * a_kq + c][a_r[i]] = rav[i] ? v : 0.f;
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) As[buf][4 * a_kq[i] + c][a_r[i]] = v[c];
             }
         }
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
-            int idx = tid + 256 * i;
-            if (idx < BN * 4) {
-                int kr = idx / (BN / 4), nq = idx % (BN / 4);
-                *reinterpret_cast<f32x4*>(&Bs[buf][kr][4 * nq]) = rw[i];
-            }
-        }
+        for (int i = 0; i < BIT; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[buf][b_kr + B_KSTEP * i][4 * b_nq]) = rw[i];
     };
 
     f32x16 acc[TM][TN];
@@ -237,18 +266,30 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) fetch(kt + 1);
+        // LDS -> register fragments are read one k-step ahead of the MFMAs that consume them
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[cur][khalf][arow + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][khalf][bcol + 32 * j];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float a[TM], b[TN];
+            const int c = ks & 1, nx = c ^ 1;
+            if (ks + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * ks + khalf][arow + 32 * i];
+                for (int i = 0; i < TM; ++i) a[nx][i] = As[cur][2 * ks + 2 + khalf][arow + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][2 * ks + khalf][bcol + 32 * j];
+                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[cur][2 * ks + 2 + khalf][bcol + 32 * j];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            // pin the order "reads of k-step ks+1, then the MFMAs of k-step ks" (hipcc otherwise sinks the
+            // reads next to their use and every k-step pays the LDS latency)
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
         if (kt + 1 < nkt) commit(cur ^ 1);
         __syncthreads();
