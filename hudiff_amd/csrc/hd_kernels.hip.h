@@ -128,19 +128,35 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, int PRO>
+// ABLATE (probe builds only, scripts/gemm_probe.hip): 1 = no global loads inside the K loop,
+// 2 = additionally no LDS commit / barrier, 3 = MFMAs only.  0 in the product.
+//
+// Structure of one block (256 threads = 4 waves as WM x WN, wave tile (BM/WM) x (BN/WN) of 32x32 MFMA tiles):
+//   K loop, BK = 32:  global -> registers for tile kt+1 is in flight while tile kt is multiplied from LDS
+//     (As[k][m], Bs[k][n], k-major so that an MFMA operand read is one conflict-free ds_read per lane);
+//     every A row is read as full 128-B lines; one LDS buffer, two barriers per k tile.
+//   Epilogue: each wave transposes its accumulators through its own slice of the (now free) LDS so that
+//     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
+//     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0>
 __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
-    constexpr int BK = 16;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int AIT = (BM * 4 + 255) / 256, BIT = (BN * 4 + 255) / 256;
-    constexpr bool A_FULL = (BM * 4) % 256 == 0;      // every thread stages A
+    constexpr int BK = 32;
+    constexpr int LDA = BM + 1, LDB = BN + 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int AIT = (BM * 8 + 255) / 256, BIT = (BN * 8) / 256;
+    constexpr bool A_FULL = (BM * 8) % 256 == 0;      // every thread stages A
+    constexpr int ES = WTN + 4;                       // epilogue staging row stride (floats)
+    constexpr int LOOP_FLOATS = BK * LDA + BK * LDB, EPI_FLOATS = 4 * 32 * ES;
+    constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS ? LOOP_FLOATS : EPI_FLOATS;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-    static_assert((BN * 4) % 256 == 0, "every thread stages W");
+    static_assert((BN * 8) % 256 == 0, "every thread stages W");
+    static_assert((BK * LDA) % 4 == 0, "Bs must stay 16-byte aligned");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    float (*As)[LDA] = reinterpret_cast<float (*)[LDA]>(smem);
+    float (*Bs)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + BK * LDA);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
     const int half = (p.taps - 1) / 2;
 
     // per-thread staging coordinates (fixed over the K loop)
-    const int a_kq = tid & 3;                         // k quad within the 16-wide k tile (same for every A row)
+    const int a_kq = tid & 7;                         // k quad within the 32-wide k tile (same for every A row)
     int a_r[AIT], a_pos[AIT];
     bool a_ok[AIT];
     long a_row[AIT];
@@ -178,27 +194,26 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
         const int idx = tid + 256 * i;
-        a_r[i] = idx >> 2;
+        a_r[i] = idx >> 3;
         const int lrow = m0 + a_r[i];
-        a_ok[i] = (A_FULL || idx < BM * 4) && (lrow < seg_rows);
+        a_ok[i] = (A_FULL || idx < BM * 8) && (lrow < seg_rows);
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;  // clamped: always a readable row
         a_st[i] = make_float2(0.f, 0.f);
         if (PRO && !CONV) a_st[i] = p.stats[a_row[i]];
     }
-    const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);          // + (256 / (BN/4)) * i rows per iteration
     constexpr int B_KSTEP = 256 / (BN / 4);
+    const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);
     const int b_col = n0 + 4 * b_nq;
-    const bool b_ok = b_col < N;
-    const int b_colc = b_ok ? b_col : 0;
+    const int b_colc = b_col < N ? b_col : 0;
 
     f32x4 ra[AIT], rw[BIT], rg, rb;
     float2 rst[AIT];
     bool rav[AIT];
 
     // Loads are unconditional (addresses clamped to something readable) and invalid lanes are zeroed at
-    // commit time: no divergent branch sits between a load and its use, so hipcc can issue the whole
-    // k-tile's loads back to back and overlap them with the MFMAs of the current tile.
+    // commit time: no divergent branch or select sits between a load and the MFMAs, so the whole k tile's
+    // loads are issued back to back and stay in flight under the MFMAs of the current tile.
     auto fetch = [&](int kt) {
         const int tap = CONV ? kt / nkt_tap : 0;
         const int kk0 = (CONV ? kt % nkt_tap : kt) * BK;
@@ -226,27 +241,27 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
             const int kr = b_kr + B_KSTEP * i;
-            const bool v = b_ok && (kk0 + kr < Kc);
-            const long wrow = v ? (long)(tap * Kc + kk0 + kr) : 0;
+            const long wrow = (kk0 + kr < Kc) ? (long)(tap * Kc + kk0 + kr) : 0;
+            // no zeroing: rows beyond Kc meet A values that commit() zeroes, columns beyond N are never
+            // stored, and the clamped address always holds finite weights (0 * finite = 0)
             rw[i] = *reinterpret_cast<const f32x4*>(W + wrow * N + b_colc);
-            if (!v) { rw[i][0] = 0.f; rw[i][1] = 0.f; rw[i][2] = 0.f; rw[i][3] = 0.f; }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            if (A_FULL || tid + 256 * i < BM * 4) {
+            if (A_FULL || tid + 256 * i < BM * 8) {
                 const float2 st = CONV ? rst[i] : a_st[i];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = pro_f<PRO>(ra[i][c], st.x, st.y, rg[c], rb[c]);
-                    As[buf][4 * a_kq + c][a_r[i]] = rav[i] ? v : 0.f;
+                    As[4 * a_kq + c][a_r[i]] = rav[i] ? v : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf][b_kr + B_KSTEP * i][4 * b_nq]) = rw[i];
+            *reinterpret_cast<f32x4*>(&Bs[b_kr + B_KSTEP * i][4 * b_nq]) = rw[i];
     };
 
     f32x16 acc[TM][TN];
@@ -258,28 +273,32 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     fetch(0);
-    commit(0);
+    commit();
     __syncthreads();
-    const int arow = wm * (BM / WM) + (lane & 31);
-    const int bcol = wn * (BN / WN) + (lane & 31);
+    const int arow = wm * WTM + (lane & 31);
+    const int bcol = wn * WTN + (lane & 31);
     const int khalf = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) fetch(kt + 1);
+        if (ABLATE == 0 && kt + 1 < nkt) fetch(kt + 1);
         // LDS -> register fragments are read one k-step ahead of the MFMAs that consume them
         float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = As[cur][khalf][arow + 32 * i];
+        for (int i = 0; i < TM; ++i) a[0][i] = As[khalf][arow + 32 * i];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][khalf][bcol + 32 * j];
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[khalf][bcol + 32 * j];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int c = ks & 1, nx = c ^ 1;
-            if (ks + 1 < BK / 2) {
+            if (ABLATE == 3) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[nx][i] = As[cur][2 * ks + 2 + khalf][arow + 32 * i];
+                for (int i = 0; i < TM; ++i) a[nx][i] = a[c][i];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[cur][2 * ks + 2 + khalf][bcol + 32 * j];
+                for (int j = 0; j < TN; ++j) b[nx][j] = b[c][j];
+            } else if (ks + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nx][i] = As[2 * ks + 2 + khalf][arow + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[2 * ks + 2 + khalf][bcol + 32 * j];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -291,11 +310,14 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (kt + 1 < nkt) commit(cur ^ 1);
-        __syncthreads();
+        if (ABLATE < 2) {
+            __syncthreads();                          // every wave is done reading this tile
+            if (kt + 1 < nkt) commit();
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue --------------------------------------------------------------------------
+    // ---- epilogue --------------------------------------------------------------------------------
     const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
     uint32_t k0 = 0, k1 = 0, row0 = 0;
     if (p.drop_mode == DROP_GEN) {
@@ -303,39 +325,60 @@ __global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
         philox4x32_10(0u, 0u, p.rs->step, p.drop_site, p.rs->seed_lo, p.rs->seed_hi, o);
         k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
     }
+    float* stage = smem + wave * (32 * ES);           // private to this wave: no block barrier needed
+    constexpr int LPR = WTN / 4;                      // lanes per staged row (float4 each)
+    constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+    const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
+    const int col = n0 + wn * WTN + e_c4;
+    const bool col_ok = col < N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lrow = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (lrow >= seg_rows) continue;
-            const long grow = (long)rbase + lrow;
-            int b = 0, slot = 0;
-            uint32_t rk = 0;
-            if (p.drop_mode != DROP_NONE) {
-                b = lrow / Lc;
-                slot = p.sg.off[seg] + (lrow - b * Lc);
-                if (p.drop_mode == DROP_GEN) rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
-            }
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (BN / WN) + 32 * j + (lane & 31);
-                if (col >= N) continue;
-                float v = acc[i][j][r];
-                if (bias) v += bias[col];
-                v = act_f(v, p.epi_act);
-                if (p.resid) v += p.resid[grow * p.ldr + col];
-                if (p.drop_mode == DROP_GEN) {
-                    uint32_t w = mix32(rk + (uint32_t)(slot * N + col) * 0x9E3779B9U);
-                    v = (w >= p.drop_thresh) ? v * p.drop_scale : 0.f;
-                } else if (p.drop_mode == DROP_INJECT) {
-                    uint8_t keep = p.drop_mask[((long)b * p.sg.L + slot) * N + col];
-                    v = keep ? v * p.drop_scale : 0.f;
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * ES + 32 * j + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + e_r;
+            const int lrow = m0 + wm * WTM + 32 * i + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
+            if (lrow < seg_rows && col_ok) {
+                const long grow = (long)rbase + lrow;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
+                if (p.resid) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + col);
+                    v += rv;
                 }
-                if (p.extra) v += p.extra[grow * p.lde + col];
-                p.C[grow * p.ldc + col] = v;
+                if (p.drop_mode != DROP_NONE) {
+                    const int b = lrow / Lc;
+                    const int slot = p.sg.off[seg] + (lrow - b * Lc);
+                    if (p.drop_mode == DROP_GEN) {
+                        const uint32_t rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t w = mix32(rk + (uint32_t)(slot * N + col + c) * 0x9E3779B9U);
+                            v[c] = (w >= p.drop_thresh) ? v[c] * p.drop_scale : 0.f;
+                        }
+                    } else {
+                        const uint8_t* mk = p.drop_mask + ((long)b * p.sg.L + slot) * N + col;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = mk[c] ? v[c] * p.drop_scale : 0.f;
+                    }
+                }
+                if (p.extra) {
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(p.extra + grow * p.lde + col);
+                    v += ev;
+                }
+                *reinterpret_cast<f32x4*>(p.C + grow * p.ldc + col) = v;
             }
         }
+        __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
     }
 }
 
