@@ -139,7 +139,7 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
 //     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
 //     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
 template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0>
-__global__ void __launch_bounds__(256) gemm_k(const GemmP p) {
+__global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
     constexpr int BK = 32;
     constexpr int LDA = BM + 1, LDB = BN + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
