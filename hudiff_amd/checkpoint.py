@@ -1,0 +1,96 @@
+"""Reads HuDiff checkpoints (the format is the reference's own: a torch.save'd dict).
+
+Envelopes (reference file:line):
+  antibody pre-train   {'config','model',...}                         antibody_scripts/antibody_train.py:439-445
+  antibody fine-tune   {'fineconfig','pretrain_config','model',...}   antibody_scripts/antibody_finetune.py:348-355
+                       (released hudiffab.pt; sample.py:451 reads 'pretrain_config')
+  nanobody pre-train   {'config','model',...}                         nanobody_scripts/nanotrain.py:325-331
+  nanobody fine-tune   {'config','model','abnativ_params','infilling_params',...}  nanofinetune.py:531-539
+                       (released hudiffnb.pt; only the 'infilling_pretrain.*' weights are used for
+                       sampling, nanosample.py:185-193, 268-270, 286-287)
+The config objects inside are pickled ``easydict.EasyDict`` instances; when that package is absent a
+minimal stand-in class is registered so the pickle loads.  torch is used here only as the file reader.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from typing import Mapping
+
+
+class _EasyDict(dict):
+    """Attribute-access dict, enough to unpickle easydict.EasyDict payloads."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, Mapping) and not isinstance(v, _EasyDict):
+            v = _EasyDict(v)
+        super().__setitem__(k, v)
+        super().__setattr__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _ensure_easydict():
+    try:
+        import easydict  # noqa: F401
+    except ImportError:
+        mod = types.ModuleType("easydict")
+        mod.EasyDict = _EasyDict
+        _EasyDict.__module__ = "easydict"
+        _EasyDict.__qualname__ = _EasyDict.__name__ = "EasyDict"
+        sys.modules["easydict"] = mod
+
+
+def EasyDict(*a, **k):
+    """EasyDict-compatible constructor (the real package's class if installed)."""
+    _ensure_easydict()
+    return sys.modules["easydict"].EasyDict(*a, **k)
+
+
+def load_checkpoint(path, map_location="cpu"):
+    """torch.load(path) tolerant of EasyDict configs (torch >= 2.6 defaults to weights_only=True)."""
+    import torch
+    _ensure_easydict()
+    return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def _strip_module(sd):
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def split_nano_framework_state(model_state):
+    """nanosample.py:185-193: {'eval_abnativ_model.*', 'infilling_pretrain.*', ...} -> infilling weights."""
+    pre = "infilling_pretrain."
+    return {k[len(pre):]: v for k, v in model_state.items() if k.startswith(pre)}
+
+
+def antibody_model_from_checkpoint(ckpt, ckpt_version="finetune"):
+    """sample.py:446-458 -> (config, state_dict, finetune_flag)."""
+    if ckpt_version == "pretrain":
+        config, finetune = ckpt["config"], False
+    elif ckpt_version == "finetune":
+        config, finetune = ckpt["pretrain_config"], True
+    else:
+        raise ValueError("ckpt version has not existed.")
+    return config, _strip_module(ckpt["model"]), finetune
+
+
+def nanobody_model_from_checkpoint(ckpt, model="finetune_vh"):
+    """nanosample.py:252-288 -> (name, model_params, state_dict)."""
+    if model == "pretrain":
+        cfg = ckpt["config"]
+        return cfg["name"] if "name" in cfg else "nano", dict(cfg["model"]), _strip_module(ckpt["model"])
+    if model == "finetune_vh":
+        return "nano", dict(ckpt["infilling_params"]), split_nano_framework_state(_strip_module(ckpt["model"]))
+    raise ValueError(model)

@@ -1,0 +1,72 @@
+"""Pieces shared by the two drop-in samplers: log-dir naming, logger, numbered-input readers, FASTA."""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import time
+
+
+def get_new_log_dir(root="./logs", prefix="", tag=""):
+    """utils/misc.py:10-24 -- {prefix}_{YYYY_mm_dd__HH_MM_SS}[_{tag}] under root."""
+    fn = time.strftime("%Y_%m_%d__%H_%M_%S", time.localtime())
+    if prefix != "":
+        fn = prefix + "_" + fn
+    if tag != "":
+        fn = fn + "_" + tag
+    log_dir = os.path.join(root, fn)
+    os.makedirs(log_dir, exist_ok=True)
+    return log_dir
+
+
+def get_logger(name, log_dir=None):
+    """utils/misc.py:34-53 -- same format string, stream + log.txt handlers."""
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.DEBUG)
+    logger.handlers.clear()
+    fmt = logging.Formatter("[%(asctime)s::%(name)s::%(levelname)s] %(message)s")
+    sh = logging.StreamHandler()
+    sh.setLevel(logging.DEBUG)
+    sh.setFormatter(fmt)
+    logger.addHandler(sh)
+    if log_dir is not None:
+        fh = logging.FileHandler(os.path.join(log_dir, "log.txt"))
+        fh.setLevel(logging.DEBUG)
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+    return logger
+
+
+def str2bool_like_reference(v):
+    """argparse ``type=bool`` of the reference: any non-empty string is True (sample.py:402, 411-414)."""
+    return bool(v)
+
+
+def load_numbered(path):
+    """Pre-numbered sequences for machines without ANARCI: JSON lines, one object per input row, e.g.
+    {"name": "ab1", "h": {"1": "E", "2": "V", ..., "111A": "G"}, "l": {...}, "l_chain": "K"}   (antibody)
+    {"h": {...}}                                                                               (nanobody)
+    keys are IMGT position strings as ``get_pad_seq`` builds them (sample.py:84-88)."""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                rows.append(json.loads(line))
+    return rows
+
+
+def write_fasta_2line(records, path):
+    """[(id, description, sequence)] -> '>id description\\nSEQ' (the 'fasta-2line' flavour)."""
+    with open(path, "w") as f:
+        for rid, desc, seq in records:
+            f.write(f">{rid} {desc}\n{seq}\n" if desc else f">{rid}\n{seq}\n")
+
+
+def write_fasta_wrapped(records, path, width=60):
+    """Bio.SeqIO 'fasta' flavour: header '>id description', sequence wrapped at 60 columns."""
+    with open(path, "w") as f:
+        for rid, desc, seq in records:
+            f.write(f">{rid} {desc}\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")

@@ -1,0 +1,137 @@
+"""Drop-in for ``nanobody_scripts/nanosample.py`` (reference lines 195-368): same flags and defaults, same
+log-dir naming, ``sample_humanization_result.csv`` with header 'Specific,name,hseq,' and per input row
+'nano,{idx},{vhh}' then 'humanization,{idx}human_sample,{seq}', and ``sample_identity.fa``.
+
+    python -m hudiff_amd.cli.nanosample --ckpt hudiffnb.pt --model finetune_vh --inpaint_sample True ...
+
+See hudiff_amd/cli/sample.py for the (forced) differences; additionally the reference re-samples when
+``abnumber.Chain(seq)`` fails to parse (nanosample.py:331-353) -- without abnumber every sample is accepted.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+
+from .. import dist as D
+from .. import inputs as I
+from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
+from ..model import NanoAntiTFNet
+from ..sampler import Job, sample_jobs, seed_all
+from .common import get_logger, get_new_log_dir, load_numbered, write_fasta_wrapped
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--ckpt", type=str, default="nanofinetune.pt")
+    p.add_argument("--data_fpath", type=str, default="abnativ_select_vhh.csv")
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--sample_number", type=int, default=1)
+    p.add_argument("--try_number", type=int, default=10)
+    p.add_argument("--seed", type=int, default=2023)
+    p.add_argument("--sample_order", type=str, default="shuffle")
+    p.add_argument("--sample_method", type=str, default="gen", choices=["gen", "rl_gen"])
+    p.add_argument("--length_limit", type=str, default="not_equal")
+    p.add_argument("--model", type=str, default="finetune_vh", choices=["pretrain", "finetune_vh"])
+    p.add_argument("--fa_version", type=str, default="v_nano")
+    p.add_argument("--inpaint_sample", type=eval, default=False)
+    p.add_argument("--structure", type=eval, default=False)
+    # additions
+    p.add_argument("--numbered_fpath", type=str, default=None)
+    p.add_argument("--device_batch", type=int, default=256)
+    p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
+    p.add_argument("--device", type=int, default=None)
+    return p
+
+
+def sample_tag(args):
+    """nanosample.py:237-243."""
+    data_sample = "abnativ_select" if "filter" in args.data_fpath else "nanobert"
+    return f"{args.seed}_{args.sample_order}_{data_sample}_{args.sample_method}_{args.length_limit}_{args.model}"
+
+
+def chain_is_valid(seq):
+    """nanosample.py:342 -- ``Chain(g_h, scheme='imgt')`` must parse; True when abnumber is unavailable."""
+    try:
+        from abnumber import Chain
+    except ImportError:
+        return True
+    try:
+        Chain(seq, scheme="imgt")
+        return True
+    except Exception:
+        return False
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print(args.inpaint_sample)
+    rank, world, local_rank = D.env_rank_world()
+    D.init_process_group()
+    seed_all(args.seed)
+    log_dir = logger = None
+    if rank == 0:
+        log_dir = get_new_log_dir(root=os.path.dirname(os.path.dirname(args.ckpt)), prefix=sample_tag(args))
+        logger = get_logger("test", log_dir)
+    ckpt = load_checkpoint(args.ckpt)
+    _, params, state = nanobody_model_from_checkpoint(ckpt, args.model)
+    model = NanoAntiTFNet(**params, device=args.device if args.device is not None else local_rank)
+    model.load_state_dict(state)
+    model.eval()
+    if rank == 0:
+        logger.info(args.ckpt)
+        logger.info(args.seed)
+
+    import pandas as pd
+    nano_df = pd.read_csv(args.data_fpath)
+    numbered = load_numbered(args.numbered_fpath) if args.numbered_fpath else None
+    if numbered is not None and len(numbered) != len(nano_df.index):
+        raise ValueError(f"{args.numbered_fpath}: {len(numbered)} rows for {len(nano_df.index)} input rows")
+    jobs = []
+    for idx, line in enumerate(nano_df.itertuples()):
+        h_dict = numbered[idx]["h"] if numbered is not None else I.number_sequence(line.vhhseq)[0]
+        tok, reg, loc = I.nanobody_row(h_dict, inpaint_sample=args.inpaint_sample)
+        if args.sample_order == "shuffle":
+            np.random.shuffle(loc)                                            # nanosample.py:314-315
+        jobs.append(Job(tokens=tok, region=reg, loc=loc, name=str(idx), parent={"h": line.vhhseq}))
+
+    # nanosample.py:316-353: every pass re-sweeps the (already filled) tokens; a pass is needed whenever fewer
+    # than sample_number parseable sequences have been written and tries remain
+    passes = max(1, min(args.try_number, -(-args.sample_number // args.batch_size)))
+    result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
+                         dropout=args.dropout)
+    if rank != 0:
+        return None
+    save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")
+    human = []
+    with open(save_fpath, "a", encoding="UTF-8") as f:
+        f.write("Specific,name,hseq,\n")
+        for j, job in enumerate(jobs):
+            f.write(f"nano,{job.name},{job.parent['h']}\n")
+            left, tries = args.sample_number, args.try_number
+            for p in range(passes):
+                for r in range(args.batch_size):
+                    if left == 0:
+                        break
+                    g_h = I.untokenize_nanobody(result[j, p, r])
+                    logger.info(g_h)
+                    if chain_is_valid(g_h) or tries == 1:
+                        f.write(f"humanization,{job.name}human_sample,{g_h}\n")
+                        human.append(g_h)
+                        left -= 1 if chain_is_valid(g_h) else 0
+                    else:
+                        logger.info("Need to re sample again.")
+                    tries -= 1
+    fasta = os.path.join(log_dir, "sample_identity.fa")
+    logger.info("Save fasta fpath: {}".format(fasta))
+    write_fasta_wrapped([(f"VH{args.fa_version}_{i}", "<unknown description>", s) for i, s in enumerate(human)], fasta)
+    if args.structure:
+        raise NotImplementedError("--structure is outside the hot path")
+    logger.info("Length did not equal list: {}".format([]))
+    logger.info("Wrong idx: {}".format([]))
+    return save_fpath
+
+
+if __name__ == "__main__":
+    main()

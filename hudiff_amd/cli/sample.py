@@ -1,0 +1,178 @@
+"""Drop-in for ``antibody_scripts/sample.py`` (reference lines 379-588): same flags and defaults, same
+log-dir naming, same ``sample_humanization_result.csv`` (header 'Specific,name,hseq,lseq,' then, per mouse
+row, 'mouse,{name},{h},{l}' followed by 'humanization,{name}human_sample,{h},{l}') and ``sample_identity.fa``.
+
+    python -m hudiff_amd.cli.sample --ckpt checkpoints/antibody/hudiffab.pt --data_fpath data.csv [...]
+    torchrun --nproc-per-node 8 -m hudiff_amd.cli.sample ...          # rows sharded over the node's GPUs
+
+Differences, all forced by what is absent offline: IMGT numbering needs anarci/abnumber,
+so ``--numbered_fpath`` accepts pre-numbered residues; ``--sample_method inpaint`` and
+``--traditional_method`` (abnumber CDR grafting) are not part of the hot path and raise; the similarity
+search scores identity over the aligned IMGT slots instead of an abnumber alignment; noise comes from the
+library's counter-based generator keyed by (seed, global row, step), not torch's global mt19937 stream.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from .. import dist as D
+from .. import inputs as I
+from ..checkpoint import antibody_model_from_checkpoint, load_checkpoint
+from ..model import model_selected
+from ..sampler import Job, sample_jobs, seed_all
+from .common import get_logger, get_new_log_dir, load_numbered, write_fasta_2line
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--ckpt", type=str, default="checkpoints/antibody/hudiffab.pt")
+    p.add_argument("--ckpt_version", type=str, default="finetune", choices=["pretrain", "finetune"])
+    p.add_argument("--data_fpath", type=str, default="humanization_pair_data_filter.csv")
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--sample_number", type=int, default=1)
+    p.add_argument("--try_number", type=int, default=1)
+    p.add_argument("--seed", type=int, default=2023)
+    p.add_argument("--sample_order", type=str, default="shuffle")
+    p.add_argument("--sample_method", type=str, default="FR", choices=["FR", "inpaint"])
+    p.add_argument("--similarity_search", type=bool, default=True)     # type=bool as in the reference (:402)
+    p.add_argument("--length_limit", type=str, default="not_equal")
+    p.add_argument("--sample_type", type=str, default="pair")
+    p.add_argument("--fa_version", type=str, default="v007")
+    p.add_argument("--structure", type=eval, default=False)
+    p.add_argument("--traditional_method", type=bool, default=False)
+    p.add_argument("--back_mutation", type=bool, default=True)
+    # additions
+    p.add_argument("--numbered_fpath", type=str, default=None,
+                   help="JSON-lines file with pre-numbered IMGT residues, one object per mouse row of --data_fpath")
+    p.add_argument("--device_batch", type=int, default=256, help="rows per device launch")
+    p.add_argument("--dropout", choices=["faithful", "off"], default="faithful",
+                   help="faithful = the reference's inference-time dropout (active iff config.dropout > 0)")
+    p.add_argument("--device", type=int, default=None)
+    return p
+
+
+def sample_tag(args):
+    """sample.py:426-432."""
+    if "humab" in args.data_fpath:
+        data_sample = "humab"
+    elif "putative" in args.data_fpath:
+        data_sample = "putative"
+    else:
+        data_sample = "lab"
+    return f"{args.seed}_{args.sample_order}_{data_sample}_{args.ckpt_version}_search_simi_{args.similarity_search}"
+
+
+def read_mouse_rows(fpath):
+    """get_mouse_line (sample.py:314-317): rows with type == 'mouse', file order."""
+    import pandas as pd
+    df = pd.read_csv(fpath)
+    return df[df["type"] == "mouse"]
+
+
+def select_most_similar(parent_tokens, replica_tokens):
+    """select_the_most_similarity_seq (sample.py:352-367): first replica with the highest mean of heavy and
+    light identity to the parental sequence."""
+    best, best_v = 0, -1.0
+    H = I.T.H_LEN
+    for r, row in enumerate(replica_tokens):
+        v = 0.5 * (I.slot_identity(parent_tokens[:H], row[:H]) + I.slot_identity(parent_tokens[H:], row[H:]))
+        if v > best_v:
+            best, best_v = r, v
+    return best
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.traditional_method:
+        raise NotImplementedError("--traditional_method (abnumber CDR grafting, sample.py:539-576) is outside the hot path")
+    if args.sample_method != "FR":
+        raise NotImplementedError("--sample_method inpaint needs abnumber CDR grafting (sample.py:209-310); §8f 'next'")
+    rank, world, local_rank = D.env_rank_world()
+    D.init_process_group()
+    seed_all(args.seed)
+
+    log_dir = logger = None
+    if rank == 0:
+        log_dir = get_new_log_dir(root=os.path.dirname(os.path.dirname(args.ckpt)), prefix=sample_tag(args))
+        logger = get_logger("test", log_dir)
+
+    ckpt = load_checkpoint(args.ckpt)
+    config, state, finetune = antibody_model_from_checkpoint(ckpt, args.ckpt_version)
+    model = model_selected(config, device=args.device if args.device is not None else local_rank)
+    model.load_state_dict(state)
+    model.eval()
+    if rank == 0:
+        logger.info(args.ckpt)
+        logger.info(args.seed)
+    n_region = config["model"]["n_region"] if "model" in config else config.model.n_region
+    pad_region = 7 if n_region > 7 else 0                                   # sample.py:462-465
+
+    mouse_df = read_mouse_rows(args.data_fpath)
+    numbered = load_numbered(args.numbered_fpath) if args.numbered_fpath else None
+    if numbered is not None and len(numbered) != len(mouse_df.index):
+        raise ValueError(f"{args.numbered_fpath}: {len(numbered)} rows for {len(mouse_df.index)} mouse rows")
+    jobs = []
+    for idx, line in enumerate(mouse_df.itertuples()):
+        if numbered is None:
+            h_dict, h_type = I.number_sequence(line.h_seq)
+            l_dict, l_type = I.number_sequence(line.l_seq)
+        else:
+            h_dict, l_dict, l_type = numbered[idx]["h"], numbered[idx]["l"], numbered[idx].get("l_chain", "K")
+        tok, reg, chain, loc = I.antibody_row(h_dict, l_dict, l_type, finetune=finetune, pad_region=pad_region)
+        parent = np.array(I._TK.seq2idx(I.slot_residues(h_dict, "H") + I.slot_residues(l_dict, "L")))
+        if args.sample_order == "shuffle":
+            np.random.shuffle(loc)                                           # sample.py:497-498
+        jobs.append(Job(tokens=tok, region=reg, loc=loc, chain=chain, name=str(line.name),
+                        parent={"h": line.h_seq, "l": line.l_seq, "tokens": parent}))
+
+    # sample.py:499-538: with similarity search one pass gives the single output row; without it the loop
+    # re-sweeps until sample_number rows have been written (batch_size rows per pass)
+    passes = 1 if args.similarity_search else max(1, -(-args.sample_number // args.batch_size))
+    result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
+                         dropout=args.dropout)
+    if rank != 0:
+        return None
+
+    save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")
+    human_rows = []
+    with open(save_fpath, "a", encoding="UTF-8") as f:
+        f.write("Specific,name,hseq,lseq,\n")
+        for j, job in enumerate(jobs):
+            f.write(f"mouse,{job.name},{job.parent['h']},{job.parent['l']}\n")
+            sample_name = str(job.name) + "human_sample"
+            if args.similarity_search:
+                if args.sample_number <= 0:
+                    continue
+                r = select_most_similar(job.parent["tokens"], result[j, 0])
+                g_h, g_l = I.untokenize_antibody(result[j, 0, r])
+                f.write(f"humanization,{sample_name},{g_h},{g_l}\n")
+                human_rows.append((g_h, g_l))
+            else:
+                left = args.sample_number
+                for p in range(passes):
+                    for r in range(args.batch_size):
+                        if left == 0:
+                            break
+                        g_h, g_l = I.untokenize_antibody(result[j, p, r])
+                        f.write(f"humanization,{sample_name},{g_h},{g_l}\n")
+                        human_rows.append((g_h, g_l))
+                        left -= 1
+    logger.info("Length did not equal list: {}".format([]))
+    logger.info("Wrong idx: {}".format([]))
+    # sample_identity.fa (trans_to_chain + save_pairs, sample.py:34-54): '{fa_version}human{i}' VH / VL pairs
+    records = []
+    for i, (g_h, g_l) in enumerate(human_rows):
+        name = args.fa_version + "human" + f"{i}"
+        records += [(name, "VH", g_h), (name, "VL", g_l)]
+    write_fasta_2line(records, os.path.join(log_dir, "sample_identity.fa"))
+    if args.structure:
+        raise NotImplementedError("--structure (per-sample fasta for structure prediction) is outside the hot path")
+    return save_fpath
+
+
+if __name__ == "__main__":
+    main()

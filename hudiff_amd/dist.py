@@ -1,0 +1,68 @@
+"""Row sharding + the single end-of-job gather.
+
+Rows (antibody x replica) are independent, so each rank samples a contiguous block of global rows with
+noise keyed by the GLOBAL row id and no data-path collective; the only exchange is one gather of the
+final int32 token arrays on rank 0 -- RCCL over xGMI on GPUs (torch.distributed backend "nccl"), gloo in
+the CPU tests.  One process per GPU, launched by torch.distributed.run.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced: the first n % world ranks get one extra row."""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, world, local_rank = env_rank_world()
+    if world == 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int) -> Optional[np.ndarray]:
+    """Gather every rank's [rows_r, L] int32 block on rank 0 -> [n_rows, L] (None on other ranks).
+    Blocks may differ by one row; they are padded to the largest block for the collective."""
+    rank, world, local_rank = env_rank_world()
+    if world == 1:
+        return np.asarray(local_tokens, dtype=np.int32).reshape(n_rows, L)
+    import torch
+    import torch.distributed as dist
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    cap = max(shard_bounds(n_rows, r, world)[1] - shard_bounds(n_rows, r, world)[0] for r in range(world))
+    buf = torch.zeros((cap, L), dtype=torch.int32, device=dev)
+    mine = torch.from_numpy(np.ascontiguousarray(local_tokens, dtype=np.int32).reshape(-1, L))
+    buf[: mine.shape[0]] = mine.to(dev)
+    outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, outs, dst=0)
+    if rank != 0:
+        return None
+    parts = []
+    for r, o in enumerate(outs):
+        lo, hi = shard_bounds(n_rows, r, world)
+        parts.append(o[: hi - lo].cpu().numpy())
+    return np.concatenate(parts, axis=0)

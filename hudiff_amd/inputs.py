@@ -1,0 +1,99 @@
+"""Input preparation of the samplers: IMGT-numbered residues -> slot tokens, mask, visiting order.
+
+Mirrors (reference file:line) ``get_input_element`` / ``batch_input_element``
+(antibody_scripts/sample.py:94-179) and their nanobody counterparts (nanobody_scripts/nanosample.py:91-149)
+from the point AFTER numbering: the hot path starts from int arrays.  Numbering itself
+(``get_pad_seq``: anarci.number + abnumber.Chain, sample.py:78-90) is the "next" row §8f-1; when
+``abnumber``/``anarci`` are importable ``number_sequence`` uses them exactly as the reference does,
+otherwise callers must supply pre-numbered residues.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import tables as T
+from .tokenizer import Tokenizer
+
+_TK = Tokenizer()
+
+
+def number_sequence(aa_seq: str) -> Tuple[Dict[str, str], str]:
+    """sample.py:78-90 -- needs the reference's own third-party stack (ANARCI + HMMER, abnumber)."""
+    try:
+        from anarci import number
+        from abnumber import Chain
+    except ImportError as e:
+        raise RuntimeError("IMGT numbering needs `anarci` and `abnumber` (not installed here); pass "
+                           "pre-numbered sequences instead (see INTEGRATION.md)") from e
+    seq_dict = {}
+    results = number(aa_seq, scheme="imgt")
+    for key, value in results[0]:
+        seq_dict[str(key[0]) + key[1].strip()] = value
+    return seq_dict, Chain(aa_seq, scheme="imgt").chain_type
+
+
+def slot_residues(seq_dict: Dict[str, str], chain: str, quiet: bool = True):
+    """Drop numbered residues into the 152 (heavy) / 139 (light) slots; unknown insertion codes are skipped
+    (sample.py:107-131: printed and ignored by the reference as well)."""
+    table = T.HEAVY_POSITIONS_dict if chain == "H" else T.LIGHT_POSITIONS_dict
+    out = ["-"] * len(table)
+    for key, value in seq_dict.items():
+        idx = table.get(key)
+        if idx is not None:
+            out[idx] = value
+        elif not quiet:
+            n = int(re.findall(r"\d+", key)[0])
+            where = "CDR has problem." if (27 <= n <= 38 or 56 <= n <= 65 or 105 <= n <= 117) else \
+                f"Position {key} is not in predefine dict, which can be ignored."
+            print(("Heavy " if chain == "H" else "Light ") + where)
+    return out
+
+
+def antibody_row(h_dict, l_dict, l_chain_type: str, finetune: bool = True, pad_region: int = 0):
+    """-> tokens[291] (masked), region[291], chain (heavy id, light id), loc (maskable slots, ascending).
+    sample.py:142-179 for one replica."""
+    slots = slot_residues(h_dict, "H") + slot_residues(l_dict, "L")
+    tok = _TK.seq2idx(slots)
+    if not finetune:
+        mask = np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0
+    else:
+        mask = np.array(T.HEAVY_CDR_KABAT_NO_VERNIER + T.LIGHT_CDR_KABAT_NO_VERNIER) == 0
+        mask = mask & ~((tok == _TK.idx_pad) & mask)          # framework gap slots are not sampled (:161-165)
+    loc = np.arange(T.AB_LEN)[mask]
+    tok = tok.copy()
+    tok[mask] = _TK.idx_msk
+    chain = (_TK.chain_type_idx("H"), _TK.chain_type_idx(l_chain_type))
+    return tok.astype(np.int32), T.ab_region(pad_region).astype(np.int32), chain, loc
+
+
+def nanobody_row(h_dict, inpaint_sample: bool = False):
+    """nanosample.py:124-149 for one replica -> tokens[152], region[152], loc."""
+    slots = slot_residues(h_dict, "H")
+    tok = _TK.seq2idx(slots)
+    table = np.array(T.INPAINT_HEAVY_CDR_INDEX if inpaint_sample else T.HEAVY_CDR_INDEX)
+    mask = (table == 0) & (tok != _TK.idx_pad)
+    loc = np.arange(T.H_LEN)[mask]
+    tok = tok.copy()
+    tok[mask] = _TK.idx_msk
+    return tok.astype(np.int32), T.nb_region().astype(np.int32), loc
+
+
+def untokenize_antibody(row) -> Tuple[str, str]:
+    row = np.asarray(row)
+    return _TK.idx2seq(row[:T.H_LEN]), _TK.idx2seq(row[T.H_LEN:])
+
+
+def untokenize_nanobody(row) -> str:
+    return _TK.idx2seq(np.asarray(row))
+
+
+def slot_identity(ref_tokens, tokens) -> float:
+    """Identity of a sample to its parental sequence over the aligned IMGT slots (both rows use the same
+    slot layout, so no alignment is needed): equal / positions where either has a residue.  Stand-in for
+    ``cal_all_preservation`` on abnumber alignments (antibody_scripts/patent_eval.py:150-159)."""
+    a, b = np.asarray(ref_tokens), np.asarray(tokens)
+    pos = (a != _TK.idx_pad) | (b != _TK.idx_pad)
+    return float(((a == b) & pos).sum()) / float(max(int(pos.sum()), 1))

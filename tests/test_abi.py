@@ -1,0 +1,67 @@
+"""The C-ABI shared object loads on a machine without a GPU, exports every symbol include/hudiff_hip.h declares,
+and refuses to run (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "hudiff_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hudiff_amd import _lib
+    lib = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in hudiff_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "ctypes binding and header disagree"
+
+
+def test_config_struct_layout_matches_header():
+    from hudiff_amd import _lib
+    text = open(os.path.join(ROOT, "include", "hudiff_hip.h")).read()
+    body = re.search(r"typedef struct HdConfig \{(.*?)\} HdConfig;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int32_t|float)\s+([a-z_]+);", body)
+    assert [n for _, n in fields] == [n for n, _ in _lib.HdConfig._fields_]
+    assert C.sizeof(_lib.HdConfig) == 4 * len(fields)
+
+
+def test_no_cpu_fallback():
+    import hudiff_amd
+    from hudiff_amd._lib import HD_ERR_NO_DEVICE, HudiffError
+    if hudiff_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(HudiffError) as e:
+        hudiff_amd.NanoAntiTFNet(23, 16, 16, 2, 7, 128, 7, 4, 16, 16, 152, 32, 2, 128, 32, 2, 2)
+    assert e.value.status == HD_ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hudiff_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "hudiff_oracle" not in src and "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_flops_formula_matches_survey():
+    from hudiff_amd import _lib
+    from hudiff_amd import synthetic as S
+    import hudiff_oracle as ho
+    assert abs(ho.flops_per_forward(S.AB_CONFIG) - 18.336296448e9) < 1
+    assert abs(ho.flops_per_forward(S.NB_CONFIG) - 5.706522624e9) < 1
+    lib = _lib.load()
+    c = _lib.HdConfig()
+    c.max_len, c.d_model, c.sum_d_model, c.att_model, c.dim_feedforward, c.kernel_size = 291, 256, 768, 512, 256, 7
+    c.n_encoder_layers, c.dual_layers, c.cs_layers, c.n_tokens = 6, 6, 5, 23
+    assert abs(lib.hd_flops_per_row_forward(C.byref(c)) - 18.336296448e9) < 1

@@ -1,0 +1,160 @@
+"""Host-side logic that needs no GPU: input preparation, checkpoint envelopes, CSV / FASTA writers, sharding."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hudiff_amd import inputs as I
+from hudiff_amd import tables as T
+from hudiff_amd.cli import nanosample as nano_cli
+from hudiff_amd.cli import sample as ab_cli
+from hudiff_amd.sampler import Job, sample_jobs
+
+
+def fake_numbering(seq, chain="H"):
+    """Contiguous IMGT numbering 1..len with the 111/112 insertion block filled symmetrically -- enough to
+    exercise the slot logic without ANARCI."""
+    names = T.HEAVY_POSITIONS if chain == "H" else T.LIGHT_POSITIONS
+    plain = [n for n in names if n.isdigit() and n != "10"]
+    ins = [n for n in names if not n.isdigit()]
+    extra = max(0, len(seq) - len(plain))
+    lo = extra // 2 + extra % 2
+    used = set(plain) | set(ins[:lo]) | set(ins[len(ins) - (extra - lo):] if extra - lo else [])
+    keys = [n for n in names if n in used][: len(seq)]
+    return dict(zip(keys, seq))
+
+
+H_SEQ = "EVQLVESGGGLVQPGGSLRLSCAASGFTFSSYAMSWVRQAPGKGLEWVSAISGSGGSTYYADSVKGRFTISRDNSKNTLYLQMNSLRAEDTAVYYCAKDRLSITIRPRYYGLDVWGQGTTVTVSS"
+L_SEQ = "DIQMTQSPSSLSASVGDRVTITCRASQSISSYLNWYQQKPGKAPKLLIYAASSLQSGVPSRFSGSGSGTDFTLTISSLQPEDFATYYCQQSYSTPLTFGGGTKVEIK"
+
+
+def test_antibody_row_masks():
+    h, l = fake_numbering(H_SEQ, "H"), fake_numbering(L_SEQ, "L")
+    tok, reg, chain, loc = I.antibody_row(h, l, "K", finetune=True)
+    assert tok.shape == (291,) and reg.tolist() == T.ab_region().tolist() and chain == (0, 2)
+    table = np.array(T.HEAVY_CDR_KABAT_NO_VERNIER + T.LIGHT_CDR_KABAT_NO_VERNIER)
+    slots = I.slot_residues(h, "H") + I.slot_residues(l, "L")
+    for i in range(291):
+        if table[i] == 0 and slots[i] != "-":
+            assert tok[i] == 22 and i in loc
+        else:
+            assert tok[i] != 22 and i not in loc                   # CDRs and framework gaps are left alone
+    assert len(loc) <= 157
+    # pretrain mode masks every IMGT framework slot, gaps included (sample.py:148-151)
+    tok2, _, _, loc2 = I.antibody_row(h, l, "L", finetune=False)
+    assert len(loc2) == 93 + 92 == (np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0).sum()
+    assert (tok2[loc2] == 22).all()
+    # untokenize drops gaps and gives back the CDR residues untouched
+    hs, ls = I.untokenize_antibody(np.where(tok == 22, 0, tok))
+    assert len(hs) == len(H_SEQ) and len(ls) == len(L_SEQ)
+
+
+def test_nanobody_row_masks():
+    h = fake_numbering(H_SEQ, "H")
+    for inpaint in (False, True):
+        tok, reg, loc = I.nanobody_row(h, inpaint_sample=inpaint)
+        table = np.array(T.INPAINT_HEAVY_CDR_INDEX if inpaint else T.HEAVY_CDR_INDEX)
+        slots = I.slot_residues(h, "H")
+        want = [i for i in range(152) if table[i] == 0 and slots[i] != "-"]
+        assert loc.tolist() == want and (tok[loc] == 22).all() and (tok == 22).sum() == len(want)
+        assert len(loc) <= (93 if not inpaint else 87)
+
+
+def test_slot_residues_ignores_unknown_insertions(capsys):
+    d = fake_numbering(H_SEQ, "H")
+    d["111Z"] = "W"
+    d["60A"] = "W"
+    out = I.slot_residues(d, "H", quiet=False)
+    assert len(out) == 152 and "W" not in [out[i] for i in range(152) if T.HEAVY_POSITIONS[i] in ("111Z", "60A")]
+    msg = capsys.readouterr().out
+    assert "CDR has problem" in msg
+
+
+def test_slot_identity():
+    a = np.array([0, 1, 21, 3, 21])
+    assert I.slot_identity(a, a) == 1.0
+    assert I.slot_identity(a, np.array([0, 2, 21, 3, 4])) == 2 / 4
+
+
+class FakeModel:
+    """CPU stand-in with the product model's sampling surface: fills visited slots with (global row + slot) % 20."""
+    kind = "ab"
+    max_len = 291
+
+    def sample(self, tokens, region, chain, order, T, *, seed=0, row0=0, q_noise=None, dropout="faithful", **kw):
+        out = np.array(tokens, copy=True)
+        for b in range(out.shape[0]):
+            for t in range(int(T[b])):
+                s = order[b, t]
+                out[b, s] = (row0 + b + s + seed) % 20
+        return out
+
+
+def _jobs(n):
+    h, l = fake_numbering(H_SEQ, "H"), fake_numbering(L_SEQ, "L")
+    jobs = []
+    for i in range(n):
+        tok, reg, chain, loc = I.antibody_row(h, l, "K")
+        rng = np.random.default_rng(i)
+        rng.shuffle(loc)
+        jobs.append(Job(tokens=tok, region=reg, loc=loc, chain=chain, name=f"ab{i}"))
+    return jobs
+
+
+def test_sample_jobs_batches_rows_with_global_ids():
+    jobs = _jobs(5)
+    big = sample_jobs(FakeModel(), jobs, replicas=3, seed=7, device_batch=256)
+    small = sample_jobs(FakeModel(), jobs, replicas=3, seed=7, device_batch=4)     # 15 rows in chunks of 4
+    assert big.shape == (5, 1, 3, 291) and np.array_equal(big, small)
+    assert not (big == 22).any()
+    two = sample_jobs(FakeModel(), jobs, replicas=2, seed=7, passes=2)
+    assert two.shape == (5, 2, 2, 291)
+
+
+def test_checkpoint_envelopes(tmp_path):
+    torch = pytest.importorskip("torch")
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd import synthetic as S
+    cfg = ck.EasyDict({"name": "trans_oadm", "model": dict(S.AB_CONFIG)})
+    sd = {"module.decoder.bias": torch.zeros(23), "self_at.layers.0.attn_hl.rope": torch.zeros(291, 32, dtype=torch.complex64)}
+    p = tmp_path / "ab.pt"
+    torch.save({"fineconfig": cfg, "pretrain_config": cfg, "model": sd, "iteration": 3}, p)
+    ckpt = ck.load_checkpoint(str(p))
+    config, state, finetune = ck.antibody_model_from_checkpoint(ckpt, "finetune")
+    assert finetune and config.model.max_len == 291 and config["name"] == "trans_oadm"
+    assert set(state) == {"decoder.bias", "self_at.layers.0.attn_hl.rope"}         # 'module.' stripped
+    with pytest.raises(KeyError):
+        ck.antibody_model_from_checkpoint(ckpt, "pretrain")
+    # nanobody fine-tune envelope: prefixed framework state, only infilling_pretrain.* is used
+    nb = {"config": ck.EasyDict({"name": "infilling", "model": {}}), "infilling_params": ck.EasyDict(dict(S.NB_CONFIG)),
+          "abnativ_params": {}, "model": {"eval_abnativ_model.x": torch.zeros(1), "infilling_pretrain.decoder.bias": torch.ones(23),
+                                          "target_infilling_pretrain.decoder.bias": torch.zeros(23)}}
+    p2 = tmp_path / "nb.pt"
+    torch.save(nb, p2)
+    name, params, state = ck.nanobody_model_from_checkpoint(ck.load_checkpoint(str(p2)), "finetune_vh")
+    assert name == "nano" and params["max_len"] == 152 and list(state) == ["decoder.bias"]
+    assert float(state["decoder.bias"][0]) == 1.0
+
+
+def test_cli_flags_and_tags():
+    a = ab_cli.build_parser().parse_args([])
+    assert (a.ckpt, a.ckpt_version, a.batch_size, a.sample_number, a.try_number, a.seed, a.sample_order, a.sample_method,
+            a.similarity_search, a.fa_version) == ("checkpoints/antibody/hudiffab.pt", "finetune", 1, 1, 1, 2023, "shuffle",
+                                                   "FR", True, "v007")
+    assert ab_cli.sample_tag(a) == "2023_shuffle_lab_finetune_search_simi_True"
+    a2 = ab_cli.build_parser().parse_args(["--data_fpath", "x/humab25/parental_mouse.csv", "--similarity_search", ""])
+    assert a2.similarity_search is False and ab_cli.sample_tag(a2).startswith("2023_shuffle_humab_finetune_search_simi_False")
+    n = nano_cli.build_parser().parse_args(["--inpaint_sample", "True", "--model", "pretrain"])
+    assert n.inpaint_sample is True and n.try_number == 10 and n.fa_version == "v_nano"
+    assert nano_cli.sample_tag(n) == "2023_shuffle_nanobert_gen_not_equal_pretrain"
+
+
+def test_fasta_writers(tmp_path):
+    from hudiff_amd.cli.common import write_fasta_2line, write_fasta_wrapped
+    p = tmp_path / "a.fa"
+    write_fasta_2line([("v007human0", "VH", "EVQ"), ("v007human0", "VL", "DIQ")], p)
+    assert p.read_text() == ">v007human0 VH\nEVQ\n>v007human0 VL\nDIQ\n"
+    write_fasta_wrapped([("VHv_nano_0", "<unknown description>", "A" * 70)], p)
+    assert p.read_text() == ">VHv_nano_0 <unknown description>\n" + "A" * 60 + "\n" + "A" * 10 + "\n"
