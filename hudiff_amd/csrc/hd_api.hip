@@ -623,9 +623,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
     if (m->L > 160)
-        hipLaunchKernelGGL(attn_k<19>, grid, dim3(256), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
     else
-        hipLaunchKernelGGL(attn_k<10>, grid, dim3(256), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
     p = base_gemm(m, sg);
     p.A = m->ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;

@@ -555,11 +555,13 @@ constexpr int ATT_KS = 68;   // K row stride in LDS (floats): 16-B aligned, spre
 constexpr int ATT_VS = 64;
 constexpr int ATT_MAX_KT = 19;   // ceil(291 / 16)
 
+constexpr int ATT_THREADS = 512;   // 8 waves, two per SIMD: one wave's softmax / LDS latency hides under the other's MFMAs
+
 template <int NKT>
-__global__ void __launch_bounds__(256, 1) attn_k(const float* __restrict__ QKV, int ldq, int att,
-                                                  const float* __restrict__ rope_cos,
-                                                  const float* __restrict__ rope_sin,
-                                                  float* __restrict__ O, int ldo, int nhead, Segs sg) {
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
+                                                          const float* __restrict__ rope_cos,
+                                                          const float* __restrict__ rope_sin,
+                                                          float* __restrict__ O, int ldo, int nhead, Segs sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = sg.L;
     float* Ks = smem;
@@ -569,7 +571,7 @@ __global__ void __launch_bounds__(256, 1) attn_k(const float* __restrict__ QKV, 
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
 
     // ---- stage K (rotated) and V ------------------------------------------------------------
-    for (int idx = tid; idx < L * 16; idx += 256) {
+    for (int idx = tid; idx < L * 16; idx += ATT_THREADS) {
         const int key = idx >> 4, c4 = (idx & 15) * 4;
         const long row = sg.row(b, key);
         f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + koff + c4);
@@ -586,7 +588,7 @@ __global__ void __launch_bounds__(256, 1) attn_k(const float* __restrict__ QKV, 
 
     const int qi = lane & 15, g = lane >> 4;
     const int nqt = (L + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
         const long qrow = sg.row(b, qc);
@@ -601,22 +603,31 @@ __global__ void __launch_bounds__(256, 1) attn_k(const float* __restrict__ QKV, 
             qf[s][0] = (v[0] * cs.x - v[1] * sn.x) * 0.125f; qf[s][1] = (v[0] * sn.x + v[1] * cs.x) * 0.125f;
             qf[s][2] = (v[2] * cs.y - v[3] * sn.y) * 0.125f; qf[s][3] = (v[2] * sn.y + v[3] * cs.y) * 0.125f;
         }
-        // S^T tiles
+        // S^T tiles, two key tiles per pass so that two independent accumulator chains are in flight
         f32x4 st[NKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int key = kt * 16 + qi;                     // A operand row index i = lane & 15
-            key = key < L ? key : L - 1;
-            const float* kp = Ks + key * ATT_KS + 4 * g;
+        for (int kt = 0; kt < NKT; kt += 2) {
+            constexpr int dummy = 0; (void)dummy;
+            const bool two = kt + 1 < NKT;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            int key0 = kt * 16 + qi, key1 = (kt + 1) * 16 + qi;          // A operand row index i = lane & 15
+            key0 = key0 < L ? key0 : L - 1;
+            key1 = key1 < L ? key1 : L - 1;
+            const float* kp0 = Ks + key0 * ATT_KS + 4 * g;
+            const float* kp1 = Ks + key1 * ATT_KS + 4 * g;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 16 * s);
+                const f32x4 kf0 = *reinterpret_cast<const f32x4*>(kp0 + 16 * s);
+                f32x4 kf1 = kf0;
+                if (two) kf1 = *reinterpret_cast<const f32x4*>(kp1 + 16 * s);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[s][c], acc, 0, 0, 0);
+                for (int c = 0; c < 4; ++c) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[c], qf[s][c], acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[c], qf[s][c], acc1, 0, 0, 0);
+                }
             }
-            st[kt] = acc;
+            st[kt] = acc0;
+            if (two) st[kt + 1] = acc1;
             __builtin_amdgcn_sched_barrier(0);   // keep later tiles' LDS reads from being hoisted (VGPR pressure)
         }
         // softmax over keys (rows of S^T); this lane owns keys 16 kt + 4 g + r
