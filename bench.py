@@ -105,7 +105,8 @@ def main():
 
     model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
     model.load_state_dict(sd)
-    flops_row = model.flops_per_row_forward()
+    flops_row = model.flops_per_row_forward()            # canonical / algorithmic
+    flops_row_exec = model.flops_per_row_sample_step()   # executed: last attention block pruned to the visited row
 
     def barrier():
         model.sync()
@@ -159,7 +160,7 @@ def main():
         seqs = n_gpus * B * args.steps
         value = seqs / elapsed
         useful_flops = float(T.sum()) * flops_row * args.steps            # per GPU, algorithmic
-        executed_flops = float(B * Tmax) * flops_row * args.steps          # every row is computed every step
+        executed_flops = float(B * Tmax) * flops_row_exec * args.steps     # every row is computed every step
         achieved = useful_flops / (gpu_ms * 1e-3) / 1e12
         out = {
             "metric": "humanized sequences/sec (full T-step sample)",
@@ -177,7 +178,8 @@ def main():
                          "launch": "one denoiser step = one replay of the captured hipGraph (all kernels of a forward "
                                    "+ sampling), HIP events on the library's stream",
                          "flops_per_launch": B * flops_row, "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
-                         "executed_tflops": round(executed_flops / (gpu_ms * 1e-3) / 1e12, 3)},
+                         "executed_tflops": round(executed_flops / (gpu_ms * 1e-3) / 1e12, 3),
+                         "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)},
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
         }
         if args.max_t > 0:

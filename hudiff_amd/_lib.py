@@ -16,13 +16,13 @@ LIB_PATH = os.path.join(HERE, "libhudiff_hip.so")
 HD_ABI_VERSION = 1
 HD_KIND_ANTIBODY, HD_KIND_NANOBODY = 0, 1
 HD_ACT_RELU, HD_ACT_GELU = 1, 2
-HD_DROPOUT_FAITHFUL, HD_DROPOUT_OFF, HD_DROPOUT_INJECT, HD_NO_GRAPH = 0, 1, 2, 4
+HD_DROPOUT_FAITHFUL, HD_DROPOUT_OFF, HD_DROPOUT_INJECT, HD_NO_GRAPH, HD_NO_PRUNE = 0, 1, 2, 4, 8
 HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_DEVICE = range(6)
 
 EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",
     "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
-    "hd_last_run_ms", "hd_flops_per_row_forward", "hd_device_info", "hd_debug_stop_after", "hd_debug_read",
+    "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read",
 ]
 
 
@@ -75,6 +75,8 @@ def load():
     lib.hd_last_run_ms.argtypes = [vp, f32p, i32p]
     lib.hd_flops_per_row_forward.argtypes = [P(HdConfig)]
     lib.hd_flops_per_row_forward.restype = C.c_double
+    lib.hd_flops_per_row_sample_step.argtypes = [P(HdConfig)]
+    lib.hd_flops_per_row_sample_step.restype = C.c_double
     lib.hd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, i32p, P(C.c_int64)]
     lib.hd_debug_stop_after.argtypes = [vp, C.c_int32]
     lib.hd_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64]

@@ -72,6 +72,8 @@ struct Workspace {
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float2* ST = nullptr;
     float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
+    float *ATc = nullptr, *Xc = nullptr, *Qc = nullptr, *Oc = nullptr, *F1c = nullptr;   // pruned last block: [B, *]
+    float2* STc = nullptr;
     int32_t *tokens = nullptr, *tokens0 = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
     int capT = 0;
     float* qnoise = nullptr; size_t qnoise_cap = 0;
@@ -109,7 +111,7 @@ struct HdModel {
     bool s_has_q = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_B = -1; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
+    int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_steps = 0; bool timed = false;
     int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
@@ -132,6 +134,14 @@ extern "C" double hd_flops_per_row_forward(const HdConfig* c) {
     const double A = c->att_model, Fd = c->dim_feedforward, k = c->kernel_size;
     return L * (c->n_encoder_layers * (4 * d * dh + 2 * k * dh * dh) + c->dual_layers * (4 * D * Dh + 2 * k * Dh * Dh) +
                 2.0 * c->cs_layers * (8 * D * A + 4 * L * A) + c->cs_layers * 4 * D * Fd + 2 * D * c->n_tokens);
+}
+
+extern "C" double hd_flops_per_row_sample_step(const HdConfig* c) {
+    // what one step of hd_sample executes per row: the canonical forward minus the parts of the last attention
+    // block (2nd attention's query / core / out projection, feed-forward) and of the decoder that are evaluated
+    // for the visited row only
+    const double L = c->max_len, D = c->sum_d_model, A = c->att_model, Fd = c->dim_feedforward;
+    return hd_flops_per_row_forward(c) - (L - 1) * (4 * D * A + 4 * L * A + 4 * D * Fd + 2 * D * c->n_tokens);
 }
 
 extern "C" HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
@@ -506,6 +516,8 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
     HD_TRY(dalloc(ws, &ws.ST, M));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
+    HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
+    HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
     HD_TRY(dalloc(ws, &ws.tokens, M)); HD_TRY(dalloc(ws, &ws.tokens0, M)); HD_TRY(dalloc(ws, &ws.region, M)); HD_TRY(dalloc(ws, &ws.chain, (size_t)2 * B));
     HD_TRY(dalloc(ws, &ws.T, (size_t)B));
     ws.capB = B;
@@ -537,6 +549,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     }
     GemmP q = p;
     q.sg = run;
+    if (q.ldw == 0) q.ldw = q.N;
     const int rows0 = run.B * run.len[0];
     const int rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
     q.tiles0 = (rows0 + BM - 1) / BM;
@@ -652,8 +665,48 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
     return HD_OK;
 }
 
+// Last SelfAttBlock of a sampling step, from "at = x + A1(x)" (in ws.AT, statistics in ws.ST) on, evaluated only
+// for the row each sequence visits at this step (see gather_rows_k).  Result: ws.Xc [B, D] = block output rows.
+static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
+    hipStream_t st = m->stream;
+    Workspace& ws = m->ws;
+    const int D = m->D, A = m->A, Fd = m->Fd, B = sg.B;
+    Segs cs{};                      // compact [B, *] matrices: one "sequence" of B single-slot rows
+    cs.nseg = 1; cs.B = B; cs.L = 1; cs.len[0] = 1;
+    // K | V projections of LN1(at) for every row (columns [A, 3A) of the fused weight)
+    GemmP p = base_gemm(m, sg);
+    p.A = ws.AT; p.lda = D; p.W = w.a2.wqkv + A; p.ldw = 3 * A; p.bias = w.a2.bqkv + A; p.C = ws.QKV + A; p.ldc = 3 * A;
+    p.N = 2 * A; p.Kc = D; p.stats = ws.ST; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
+    launch_gemm(p, false, false, st);
+    // visited rows of `at` and of the block input x
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, m->rs, sg);
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, m->rs, sg);
+    hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
+    // q = LN1(at_c) Wq + bq
+    p = base_gemm(m, cs);
+    p.A = ws.ATc; p.lda = D; p.W = w.a2.wqkv; p.ldw = 3 * A; p.bias = w.a2.bqkv; p.C = ws.Qc; p.ldc = A; p.N = A; p.Kc = D;
+    p.stats = ws.STc; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
+    launch_gemm(p, false, false, st);
+    hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
+                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, m->rs, sg);
+    // at_c = at_c + o Wo + bo
+    p = base_gemm(m, cs);
+    p.A = ws.Oc; p.lda = A; p.W = w.a2.wo; p.bias = w.a2.bo; p.C = ws.ATc; p.ldc = D; p.N = D; p.Kc = A; p.resid = ws.ATc; p.ldr = D;
+    launch_gemm(p, false, false, st);
+    // x_c = FF(LN2(at_c)) + x_c
+    hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
+    p = base_gemm(m, cs);
+    p.A = ws.ATc; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1c; p.ldc = Fd; p.N = Fd; p.Kc = D;
+    p.stats = ws.STc; p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;
+    launch_gemm(p, false, false, st);
+    p = base_gemm(m, cs);
+    p.A = ws.F1c; p.lda = Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Xc; p.ldc = D; p.N = D; p.Kc = Fd; p.resid = ws.Xc; p.ldr = D;
+    launch_gemm(p, false, false, st);
+}
+
 // One denoiser forward up to the last attention block; result rows in ws.Y.
-static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks) {
+static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks,
+                             bool prune_last = false) {
     hipStream_t st = m->stream;
     Workspace& ws = m->ws;
     const HdConfig& c = m->cfg;
@@ -680,6 +733,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         attention_layer(m, sg, w.a1, ws.Y, false, nullptr, nullptr, ws.Y, ws.AT);
         // at = at + A2(LN1(at))
         launch_stats(m, ws.AT, D, D, rows, st);
+        if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
         attention_layer(m, sg, w.a2, ws.AT, true, w.n1_g, w.n1_b, ws.AT, ws.AT);
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         launch_stats(m, ws.AT, D, D, rows, st);
@@ -782,10 +836,11 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
 
 // ---- sampling session ---------------------------------------------------------------------------
 static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, const uint8_t* cm) {
-    HD_TRY(forward_body(m, sg, dm, em, cm));
+    const bool prune = !(m->sflags & HD_NO_PRUNE);
+    HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = m->ws;
-    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, m->stream, ws.Y, m->D, m->head, ws.tokens, ws.order, ws.T,
-                       m->sTmax, m->s_has_q ? ws.qnoise : nullptr, m->rs, sg);
+    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, m->stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
+                       ws.T, m->sTmax, m->s_has_q ? ws.qnoise : nullptr, m->rs, sg, prune ? 1 : 0);
     hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, m->stream, m->rs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
@@ -864,7 +919,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
     hipLaunchKernelGGL(set_step_k, dim3(1), dim3(1), 0, m->stream, m->rs, (uint32_t)t0);
     const bool use_graph = !(m->sflags & HD_NO_GRAPH) && dm != DROP_INJECT;
     if (use_graph) {
-        if (!m->graph_exec || m->graph_B != m->sB || m->graph_drop != dm || m->graph_q != m->s_has_q || m->graph_Tmax != m->sTmax) {
+        if (!m->graph_exec || m->graph_B != m->sB || m->graph_flags != (m->sflags & HD_NO_PRUNE) || m->graph_drop != dm || m->graph_q != m->s_has_q || m->graph_Tmax != m->sTmax) {
             if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIP_TRY(hipStreamSynchronize(m->stream));
@@ -874,7 +929,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
             if (s != HD_OK) return s;
             if (e != hipSuccess) return fail(HD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             HIP_TRY(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-            m->graph_B = m->sB; m->graph_drop = dm; m->graph_q = m->s_has_q; m->graph_Tmax = m->sTmax;
+            m->graph_B = m->sB; m->graph_flags = (m->sflags & HD_NO_PRUNE); m->graph_drop = dm; m->graph_q = m->s_has_q; m->graph_Tmax = m->sTmax;
         }
         HIP_TRY(hipEventRecord(m->ev0, m->stream));
         for (int t = t0; t < t1; ++t) HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));

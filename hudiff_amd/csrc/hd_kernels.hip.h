@@ -99,6 +99,7 @@ struct GemmP {
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
     float* C; int ldc;                // [rows, N]
     int N, Kc, taps, dil;             // K = taps * Kc
+    int ldw;                          // row stride of W (>= N; a column slice of a fused matrix has ldw > N)
     long w_stride; int n_stride; int k_stride;   // per-segment strides of W / bias / (gamma, beta)
     // prologue: LayerNorm over the Kc features of each A row, then activation
     const float2* stats;              // [rows] (mean, rstd) or null
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
             const long wrow = (kk0 + kr < Kc) ? (long)(tap * Kc + kk0 + kr) : 0;
             // no zeroing: rows beyond Kc meet A values that commit() zeroes, columns beyond N are never
             // stored, and the clamped address always holds finite weights (0 * finite = 0)
-            rw[i] = *reinterpret_cast<const f32x4*>(W + wrow * N + b_colc);
+            rw[i] = *reinterpret_cast<const f32x4*>(W + wrow * p.ldw + b_colc);
         }
     };
     auto commit = [&]() {
@@ -280,32 +281,36 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
     const int khalf = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         if (ABLATE == 0 && kt + 1 < nkt) fetch(kt + 1);
-        // LDS -> register fragments are read one k-step ahead of the MFMAs that consume them
-        float a[2][TM], b[2][TN];
+        // LDS -> register fragments are read LDS_AHEAD k-steps ahead of the MFMAs that consume them
+        constexpr int LDS_AHEAD = 2, RING = LDS_AHEAD + 1;
+        float a[RING][TM], b[RING][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = As[khalf][arow + 32 * i];
+        for (int d = 0; d < LDS_AHEAD; ++d) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = Bs[khalf][bcol + 32 * j];
+            for (int i = 0; i < TM; ++i) a[d][i] = As[2 * d + khalf][arow + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[d][j] = Bs[2 * d + khalf][bcol + 32 * j];
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            const int c = ks & 1, nx = c ^ 1;
+            const int c = ks % RING, nx = (ks + LDS_AHEAD) % RING;
             if (ABLATE == 3) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[nx][i] = a[c][i];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[nx][j] = b[c][j];
-            } else if (ks + 1 < BK / 2) {
+            } else if (ks + LDS_AHEAD < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[nx][i] = As[2 * ks + 2 + khalf][arow + 32 * i];
+                for (int i = 0; i < TM; ++i) a[nx][i] = As[2 * (ks + LDS_AHEAD) + khalf][arow + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[2 * ks + 2 + khalf][bcol + 32 * j];
+                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[2 * (ks + LDS_AHEAD) + khalf][bcol + 32 * j];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
-            // pin the order "reads of k-step ks+1, then the MFMAs of k-step ks" (hipcc otherwise sinks the
+            // pin the order "reads of a later k-step, then the MFMAs of k-step ks" (hipcc otherwise sinks the
             // reads next to their use and every k-step pays the LDS latency)
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
@@ -678,6 +683,96 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pruned last attention block (sampling only).  After the last SelfAttBlock only the row of the slot visited
+// at this step feeds the decoder (sample.py:508-513), so for that block the second attention's query side,
+// the out-projection and the feed-forward are evaluated for ONE row per sequence:
+//   gather_rows_k   compacts rows (b, slot_b) of a [rows, C] buffer into [B, C]
+//   attn_row_k      one query per (sequence, head) against all L keys / values (RoPE on the fly)
+// The K / V projections and the first attention of the block still cover every row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int step_slot(const int32_t* __restrict__ order, const int32_t* __restrict__ T,
+                                         int Tmax, int b, uint32_t t) {
+    return ((int)t < T[b]) ? order[(long)b * Tmax + t] : 0;      // finished rows: any valid slot, never written
+}
+
+__global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ src, int C, float* __restrict__ dst,
+                                                      const int32_t* __restrict__ order, const int32_t* __restrict__ T,
+                                                      int Tmax, const RunState* __restrict__ rs, Segs sg) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= sg.B) return;
+    const int slot = step_slot(order, T, Tmax, b, rs->step);
+    const float* s = src + (long)sg.row(b, slot) * C;
+    float* d = dst + (long)b * C;
+    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
+}
+
+// One wave per (sequence, head).  Qc: [B, att] compact query projection; QKV: full-row buffer holding K at column
+// `att + h*64` and V at `2*att + h*64`.  Oc: [B, att].
+__global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, const float* __restrict__ QKV, int ldq,
+                                                   int att, const float* __restrict__ rope_cos,
+                                                   const float* __restrict__ rope_sin, float* __restrict__ Oc,
+                                                   int nhead, const int32_t* __restrict__ order,
+                                                   const int32_t* __restrict__ T, int Tmax,
+                                                   const RunState* __restrict__ rs, Segs sg) {
+    __shared__ float qs[4][ATT_HD];
+    __shared__ float ps[4][320];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + w;
+    if (bh >= sg.B * nhead) return;
+    const int b = bh / nhead, h = bh % nhead, L = sg.L;
+    const int slot = step_slot(order, T, Tmax, b, rs->step);
+    {   // rotated, pre-scaled query: lane handles the complex pair (2k, 2k+1), k = lane & 31
+        const int k = lane & 31;
+        if (lane < 32) {
+            const float xr = Qc[(long)b * att + h * ATT_HD + 2 * k], xi = Qc[(long)b * att + h * ATT_HD + 2 * k + 1];
+            const float c = rope_cos[slot * 32 + k], s = rope_sin[slot * 32 + k];
+            qs[w][2 * k] = (xr * c - xi * s) * 0.125f;
+            qs[w][2 * k + 1] = (xr * s + xi * c) * 0.125f;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float sc[5];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int key = lane + 64 * i;
+        sc[i] = -INFINITY;
+        if (key < L) {
+            const float* kp = QKV + (long)sg.row(b, key) * ldq + att + h * ATT_HD;
+            float a = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + 4 * k4);
+                const float2 cs = *reinterpret_cast<const float2*>(rope_cos + key * 32 + 2 * k4);
+                const float2 sn = *reinterpret_cast<const float2*>(rope_sin + key * 32 + 2 * k4);
+                a += (kv[0] * cs.x - kv[1] * sn.x) * qs[w][4 * k4] + (kv[0] * sn.x + kv[1] * cs.x) * qs[w][4 * k4 + 1];
+                a += (kv[2] * cs.y - kv[3] * sn.y) * qs[w][4 * k4 + 2] + (kv[2] * sn.y + kv[3] * cs.y) * qs[w][4 * k4 + 3];
+            }
+            sc[i] = a;
+            mx = fmaxf(mx, a);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int key = lane + 64 * i;
+        const float e = (key < L) ? expf(sc[i] - mx) : 0.f;
+        if (key < 320) ps[w][key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // O[d] = sum_key p[key] V[key, d]; lane = d
+    float o = 0.f;
+    for (int key = 0; key < L; ++key)
+        o += ps[w][key] * QKV[(long)sg.row(b, key) * ldq + 2 * att + h * ATT_HD + lane];
+    Oc[(long)b * att + h * ATT_HD + lane] = o / sum;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Final stage of a sampling step (sample.py:508-513): for row b at its slot of this step,
 //   logits = Linear(LN(h[row]))[0:22]; p = softmax(logits); s = argmax p / q; tokens[b, slot] = s
 // one wave per sequence.  D <= 1024.
@@ -708,13 +803,14 @@ __global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm
                                                      const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ T, int Tmax,
                                                      const float* __restrict__ q_noise,
-                                                     const RunState* __restrict__ rs, Segs sg) {
+                                                     const RunState* __restrict__ rs, Segs sg, int compact) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const uint32_t t = rs->step;
     if ((int)t >= T[b]) return;
     const int slot = order[(long)b * Tmax + t];
     float y[16];
-    ln_row_regs(Hm + (long)sg.row(b, slot) * D, D, lane, w, y);
+    // compact: Hm is [B, D] holding only the visited row of each sequence (pruned last block)
+    ln_row_regs(Hm + (compact ? (long)b : (long)sg.row(b, slot)) * D, D, lane, w, y);
     float mylogit = -INFINITY;
     for (int j = 0; j < 22; ++j) {
         float a = 0.f;

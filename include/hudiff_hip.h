@@ -67,7 +67,9 @@ enum {
     HD_DROPOUT_OFF      = 1u,  /* sites are identity                                                */
     HD_DROPOUT_INJECT   = 2u,  /* caller supplies keep-masks (parity tests)                         */
     HD_DROPOUT_MASK     = 3u,
-    HD_NO_GRAPH         = 4u   /* launch kernels eagerly instead of replaying the captured hipGraph */
+    HD_NO_GRAPH         = 4u,  /* launch kernels eagerly instead of replaying the captured hipGraph */
+    HD_NO_PRUNE         = 8u   /* hd_sample: evaluate the last attention block for every row (as hd_forward
+                                  does) instead of only for the row each sequence visits at that step      */
 };
 
 /* Hyper-parameters: the `model:` section of configs/antibody_train.yml:3-24 / heavy_train.yml:3-21,
@@ -151,6 +153,8 @@ HdStatus hd_sync(HdModel* m);
 HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps);
 /* Algorithmic FLOPs of one forward of one row (SURVEY.md §8d formula). */
 double hd_flops_per_row_forward(const HdConfig* cfg);
+/* FLOPs one hd_sample step actually executes per row (last attention block pruned to the visited row). */
+double hd_flops_per_row_sample_step(const HdConfig* cfg);
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -50,6 +50,15 @@ int main() {
             t[0] = run<128, 128, 2, 2, true, 2, 0>(p, 5); t[1] = run<128, 128, 2, 2, true, 2, 1>(p, 5);
             t[2] = run<128, 128, 2, 2, true, 2, 2>(p, 5); t[3] = run<128, 128, 2, 2, true, 2, 3>(p, 5);
         }
+        if (s.taps == 1) {
+            float u0 = run<128, 256, 2, 2, false, 0, 0>(p, 5), u1 = run<128, 256, 2, 2, false, 0, 1>(p, 5);
+            float v0 = run<256, 128, 4, 1, false, 0, 0>(p, 5), v1 = run<256, 128, 4, 1, false, 0, 1>(p, 5);
+            printf("   128x256: full %7.1f us %6.1f TF no-gload %6.1f TF | 256x128: full %7.1f us %6.1f TF no-gload %6.1f TF\n",
+                   u0 * 1e3, gf / u0, gf / u1, v0 * 1e3, gf / v0, gf / v1);
+        } else {
+            float u0 = run<128, 256, 2, 2, true, 2, 0>(p, 5), v0 = run<256, 128, 4, 1, true, 2, 0>(p, 5);
+            printf("   128x256: full %7.1f us %6.1f TF | 256x128: full %7.1f us %6.1f TF\n", u0 * 1e3, gf / u0, v0 * 1e3, gf / v0);
+        }
         printf("%-22s %7.1f GF | full %7.1f us %6.1f TF | no-gload %7.1f us %6.1f TF | +no-commit/barrier %7.1f us %6.1f TF | mfma-only %7.1f us %6.1f TF\n",
                s.name, gf, t[0] * 1e3, gf / t[0], t[1] * 1e3, gf / t[1], t[2] * 1e3, gf / t[2], t[3] * 1e3, gf / t[3]);
     }

@@ -80,6 +80,17 @@ def test_full_sampling_trace_bit_exact(micro, mode, graph):
     assert np.array_equal(out, z["final"])          # identical humanized residues as the reference loop
 
 
+def test_pruned_last_block_equals_full_evaluation(micro):
+    """hd_sample evaluates the last attention block only for the visited row (HD_NO_PRUNE turns that off)."""
+    from hudiff_amd import synthetic as S
+    batch = S.synthetic_batch(micro["kind"], 6, seed=21)
+    T = batch["T"].copy(); T[2] = 3
+    kw = dict(seed=77, row0=5, dropout="faithful")
+    a = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, prune=True, **kw)
+    b = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, prune=False, **kw)
+    assert np.array_equal(a, b)
+
+
 def test_sampling_with_reference_dropout_masks(micro):
     z = load_golden(f"micro_{micro['kind']}_sample_dropout.npz")
     B, loc = z["tokens"].shape[0], z["loc"]
