@@ -571,8 +571,8 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
             default: HD_LAUNCH(true, 3); break;      // the ByteNet convolution always has LN + activation
         }
     }
-#undef HD_LAUNCH
 }
+#undef HD_LAUNCH
 
 static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     const long rows = (long)p.sg.B * p.sg.L;

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hd {
 
@@ -139,8 +140,8 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
 //   Epilogue: each wave transposes its accumulators through its own slice of the (now free) LDS so that
 //     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
 //     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
-template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0>
-__global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1>
+__global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) {
     constexpr int BK = 32;
     constexpr int LDA = BM + 1, LDB = BN + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -148,7 +149,8 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
     constexpr int AIT = (BM * 8 + 255) / 256, BIT = (BN * 8) / 256;
     constexpr bool A_FULL = (BM * 8) % 256 == 0;      // every thread stages A
     constexpr int ES = WTN + 4;                       // epilogue staging row stride (floats)
-    constexpr int LOOP_FLOATS = BK * LDA + BK * LDB, EPI_FLOATS = 4 * 32 * ES;
+    constexpr int BUF_FLOATS = BK * LDA + BK * LDB;
+    constexpr int LOOP_FLOATS = NBUF * BUF_FLOATS, EPI_FLOATS = 4 * 32 * ES;
     constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS ? LOOP_FLOATS : EPI_FLOATS;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
@@ -158,6 +160,7 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float (*As)[LDA] = reinterpret_cast<float (*)[LDA]>(smem);
     float (*Bs)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + BK * LDA);
+    static_assert(BUF_FLOATS % 4 == 0, "second buffer must stay 16-byte aligned");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -248,7 +251,9 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
             rw[i] = *reinterpret_cast<const f32x4*>(W + wrow * p.ldw + b_colc);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        float (*Aw)[LDA] = reinterpret_cast<float (*)[LDA]>(smem + buf * BUF_FLOATS);
+        float (*Bw)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + buf * BUF_FLOATS + BK * LDA);
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             if (A_FULL || tid + 256 * i < BM * 8) {
@@ -256,13 +261,13 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = pro_f<PRO>(ra[i][c], st.x, st.y, rg[c], rb[c]);
-                    As[4 * a_kq + c][a_r[i]] = rav[i] ? v : 0.f;
+                    Aw[4 * a_kq + c][a_r[i]] = rav[i] ? v : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[b_kr + B_KSTEP * i][4 * b_nq]) = rw[i];
+            *reinterpret_cast<f32x4*>(&Bw[b_kr + B_KSTEP * i][4 * b_nq]) = rw[i];
     };
 
     f32x16 acc[TM][TN];
@@ -274,36 +279,39 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     fetch(0);
-    commit();
+    commit(0);
     __syncthreads();
     const int arow = wm * WTM + (lane & 31);
     const int bcol = wn * WTN + (lane & 31);
     const int khalf = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (ABLATE == 0 && kt + 1 < nkt) fetch(kt + 1);
-        // LDS -> register fragments are read LDS_AHEAD k-steps ahead of the MFMAs that consume them
+    // MFMAs of k-steps [KS0, KS1) of the tile in LDS buffer `buf`; LDS -> register fragments are read LDS_AHEAD
+    // k-steps ahead of the MFMAs that consume them
+    auto mma = [&](int buf, auto ks0_c, auto ks1_c) {
+        constexpr int KS0 = decltype(ks0_c)::value, KS1 = decltype(ks1_c)::value;
         constexpr int LDS_AHEAD = 2, RING = LDS_AHEAD + 1;
+        float (*Ar)[LDA] = reinterpret_cast<float (*)[LDA]>(smem + buf * BUF_FLOATS);
+        float (*Br)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + buf * BUF_FLOATS + BK * LDA);
         float a[RING][TM], b[RING][TN];
 #pragma unroll
         for (int d = 0; d < LDS_AHEAD; ++d) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[d][i] = As[2 * d + khalf][arow + 32 * i];
+            for (int i = 0; i < TM; ++i) a[d][i] = Ar[2 * (KS0 + d) + khalf][arow + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[d][j] = Bs[2 * d + khalf][bcol + 32 * j];
+            for (int j = 0; j < TN; ++j) b[d][j] = Br[2 * (KS0 + d) + khalf][bcol + 32 * j];
         }
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int c = ks % RING, nx = (ks + LDS_AHEAD) % RING;
+        for (int ks = KS0; ks < KS1; ++ks) {
+            const int c = (ks - KS0) % RING, nx = (ks - KS0 + LDS_AHEAD) % RING;
             if (ABLATE == 3) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[nx][i] = a[c][i];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[nx][j] = b[c][j];
-            } else if (ks + LDS_AHEAD < BK / 2) {
+            } else if (ks + LDS_AHEAD < KS1) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[nx][i] = As[2 * (ks + LDS_AHEAD) + khalf][arow + 32 * i];
+                for (int i = 0; i < TM; ++i) a[nx][i] = Ar[2 * (ks + LDS_AHEAD) + khalf][arow + 32 * i];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[nx][j] = Bs[2 * (ks + LDS_AHEAD) + khalf][bcol + 32 * j];
+                for (int j = 0; j < TN; ++j) b[nx][j] = Br[2 * (ks + LDS_AHEAD) + khalf][bcol + 32 * j];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -315,12 +323,28 @@ __global__ void __launch_bounds__(256, 3) gemm_k(const GemmP p) {
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (ABLATE < 2) {
-            __syncthreads();                          // every wave is done reading this tile
-            if (kt + 1 < nkt) commit();
-            __syncthreads();
+    };
+    using std::integral_constant;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (ABLATE == 0 && kt + 1 < nkt) fetch(kt + 1);
+        if (NBUF == 1) {
+            mma(0, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
+            if (ABLATE < 2) {
+                __syncthreads();                      // every wave is done reading this tile
+                if (kt + 1 < nkt) commit(0);
+                __syncthreads();
+            }
+        } else {
+            // two LDS buffers: the next tile is written to the other buffer half-way through this tile's
+            // MFMAs (its loads have had half a tile to land), one barrier per k tile
+            const int cur = kt & 1;
+            mma(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+            if (ABLATE < 2 && kt + 1 < nkt) commit(cur ^ 1);
+            mma(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+            if (ABLATE < 2) __syncthreads();
         }
     }
+    if (NBUF == 2) __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------------
     const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
