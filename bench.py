@@ -82,12 +82,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Debug aid for single-GPU boxes: HUDIFF_BENCH_SHARE_GPU=1 runs every rank on device 0 with a gloo (CPU)
+    # gather, so that the N > 1 control flow can be exercised without N GPUs.  Never set by the driver.
+    share_gpu = os.environ.get("HUDIFF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     n_gpus = world
+    coll_dev = "cpu" if share_gpu else "cuda"
 
     import hudiff_amd
     from hudiff_amd import synthetic as S
@@ -143,12 +152,12 @@ def main():
     gathered = [tokens]
     if dist is not None:
         import torch
-        t = torch.from_numpy(tokens).cuda()
+        t = torch.from_numpy(tokens).to(coll_dev)
         outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
         dist.gather(t, outs, dst=0)
         if rank == 0:
             gathered = [o.cpu().numpy() for o in outs]
-        el = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device="cuda")
+        el = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed, gpu_ms = float(el[0]), float(el[1])
 
