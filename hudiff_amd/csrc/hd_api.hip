@@ -71,6 +71,7 @@ struct Workspace {
     float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float2* ST = nullptr;
+    float2* PART = nullptr;                                  // [M, PART_STRIDE] LayerNorm partials from GEMM epilogues
     float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
     float *ATc = nullptr, *Xc = nullptr, *Qc = nullptr, *Oc = nullptr, *F1c = nullptr;   // pruned last block: [B, *]
     float2* STc = nullptr;
@@ -101,6 +102,7 @@ struct HdModel {
     HeadW head{};
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     float* side_vec = nullptr;
+    float2* emb_stats = nullptr;      // [n_tokens] LayerNorm (mean, rstd) of each embedding row
     RunState* rs = nullptr;
     Workspace ws;
     // sampling session
@@ -220,6 +222,7 @@ extern "C" void hd_destroy(HdModel* m) {
     free_ws(m->ws);
     if (m->blob) hipFree(m->blob);
     if (m->side_vec) hipFree(m->side_vec);
+    if (m->emb_stats) hipFree(m->emb_stats);
     if (m->rs) hipFree(m->rs);
     if (m->ev0) hipEventDestroy(m->ev0);
     if (m->ev1) hipEventDestroy(m->ev1);
@@ -474,6 +477,8 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     m->rope_cos = B0 + o_cos; m->rope_sin = B0 + o_sin;
     HIP_TRY(hipMalloc(&m->rs, sizeof(RunState)));
     HIP_TRY(hipMemset(m->rs, 0, sizeof(RunState)));
+    HIP_TRY(hipMalloc(&m->emb_stats, sizeof(float2) * c.n_tokens));
+    hipLaunchKernelGGL(row_stats_k, dim3((c.n_tokens + 3) / 4), dim3(256), 0, m->stream, m->emb, d, d, c.n_tokens, m->emb_stats);
     if (ab) {
         HIP_TRY(hipMalloc(&m->side_vec, sizeof(float) * c.n_side * d));
         hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, m->stream, m->sidew, se, d, m->side_vec);
@@ -514,7 +519,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.QKV, M * 3 * A)); HD_TRY(dalloc(ws, &ws.O, M * A)); HD_TRY(dalloc(ws, &ws.AT, M * D));
     HD_TRY(dalloc(ws, &ws.F1, M * Fd));
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
-    HD_TRY(dalloc(ws, &ws.ST, M));
+    HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART, M * PART_STRIDE));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
@@ -574,10 +579,15 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
 }
 #undef HD_LAUNCH
 
-static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
+// p.part != nullptr: the epilogue leaves LayerNorm partials of the output rows and they are merged into `stats_out`.
+static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float2* stats_out = nullptr) {
     const long rows = (long)p.sg.B * p.sg.L;
-    if (rows >= 8192) launch_gemm_t<128, 128, 2, 2>(p, conv, per_seg, st);
+    const bool big = rows >= 8192;
+    p.part_rows = rows;
+    if (big) launch_gemm_t<128, 128, 2, 2>(p, conv, per_seg, st);
     else launch_gemm_t<32, 128, 1, 4>(p, conv, per_seg, st);
+    if (p.part && stats_out)
+        hipLaunchKernelGGL(ln_finalize_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows, stats_out);
 }
 
 static void launch_stats(const HdModel* m, const float* X, int ldx, int C, int rows, hipStream_t st) {
@@ -595,38 +605,40 @@ static void set_drop(GemmP& p, const Drop& dr) {
 }
 
 // One ByteNet block:  out = dropout(x + PFF2(act(LN(conv(act(LN(PFF1(act(LN(x))))))))))   [+ extra]
+// LayerNorm statistics travel with the data: every GEMM epilogue leaves the statistics of the rows it wrote
+// (ws.PART -> ws.ST) for the next GEMM's prologue.  x_stats_ready: ws.ST already describes x;
+// want_out_stats: leave the statistics of `out` in ws.ST for the next block.
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
-                          const Drop& dr, const float* extra, int lde) {
+                          const Drop& dr, const float* extra, int lde, bool x_stats_ready, bool want_out_stats) {
     hipStream_t st = m->stream;
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
-    launch_stats(m, x, ldx, din, rows, st);
+    if (!x_stats_ready) launch_stats(m, x, ldx, din, rows, st);
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
-    p.stats = m->ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act;
-    launch_gemm(p, false, true, st);
+    p.stats = m->ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = m->ws.PART;
+    launch_gemm(p, false, true, st, m->ws.ST);
 
-    launch_stats(m, h1, dh, dh, rows, st);
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    p.stats = m->ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act;
-    launch_gemm(p, true, true, st);
+    p.stats = m->ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act; p.part = m->ws.PART;
+    launch_gemm(p, true, true, st, m->ws.ST);
 
-    launch_stats(m, h2, dh, dh, rows, st);
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
     p.stats = m->ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     set_drop(p, dr);
-    launch_gemm(p, false, true, st);
+    if (want_out_stats) p.part = m->ws.PART;
+    launch_gemm(p, false, true, st, m->ws.ST);
 }
 
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
-                            const float* g, const float* b, const float* resid, float* out) {
+                            const float* g, const float* b, const float* resid, float* out, bool want_out_stats) {
     hipStream_t st = m->stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
@@ -642,7 +654,8 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p = base_gemm(m, sg);
     p.A = m->ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    launch_gemm(p, false, false, st);
+    if (want_out_stats) p.part = m->ws.PART;
+    launch_gemm(p, false, false, st, m->ws.ST);
 }
 
 // The token-independent branch (RegionEmbedder, PosEmbedder, SideEmbedder): once per batch.
@@ -711,32 +724,32 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     Workspace& ws = m->ws;
     const HdConfig& c = m->cfg;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
-    hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, d, ws.X, sg);
+    hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
     const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
     for (int n = 0; n < c.n_encoder_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
         bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
-                      last ? ws.EXTRA : nullptr, d);
+                      last ? ws.EXTRA : nullptr, d, /*x_stats_ready=*/true, /*want_out_stats=*/!last);
     }
     if (m->debug_stop_after == 1) return HD_OK;
     for (int n = 0; n < c.dual_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
-        bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0);
+        // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
+        bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
+                      /*x_stats_ready=*/n > 0, /*want_out_stats=*/n + 1 < c.dual_layers);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
         if (m->debug_stop_after == 2 + n) return HD_OK;
         const AttBlockW& w = m->att[n];
         // at = x + A1(x)
-        attention_layer(m, sg, w.a1, ws.Y, false, nullptr, nullptr, ws.Y, ws.AT);
-        // at = at + A2(LN1(at))
-        launch_stats(m, ws.AT, D, D, rows, st);
+        attention_layer(m, sg, w.a1, ws.Y, false, nullptr, nullptr, ws.Y, ws.AT, /*want_out_stats=*/true);
+        // at = at + A2(LN1(at))      (statistics of `at` come from the out-projection's epilogue)
         if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
-        attention_layer(m, sg, w.a2, ws.AT, true, w.n1_g, w.n1_b, ws.AT, ws.AT);
+        attention_layer(m, sg, w.a2, ws.AT, true, w.n1_g, w.n1_b, ws.AT, ws.AT, /*want_out_stats=*/true);
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
-        launch_stats(m, ws.AT, D, D, rows, st);
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
         p.stats = ws.ST; p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;

@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 enum { DROP_NONE = 0, DROP_GEN = 1, DROP_INJECT = 2 };
+constexpr int PART_STRIDE = 32;   // max column slices of a GEMM output row (N <= 1024 with 32-wide slices)
 
 struct Segs {
     int nseg;      // 1 (nanobody) or 2 (antibody: heavy, light)
@@ -79,6 +80,22 @@ __device__ __forceinline__ float act_f(float x, int act) {
     if (act == ACT_GELU) return gelu_f(x);
     return x;
 }
+// Sum over groups of N (8 or 16) consecutive lanes with DPP cross-lane moves (single VALU ops, no LDS crossbar):
+// quad butterfly (xor 1, xor 2), then row_half_mirror (lane i <- 7 - i) and row_mirror (lane i <- 15 - i).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(N == 8 || N == 16, "group of 8 or 16 lanes");
+    v += dpp_f<0xB1>(v);       // quad_perm(1,0,3,2)
+    v += dpp_f<0x4E>(v);       // quad_perm(2,3,0,1)
+    v += dpp_f<0x141>(v);      // row_half_mirror
+    if (N == 16) v += dpp_f<0x140>(v);   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -113,6 +130,7 @@ struct GemmP {
     int drop_mode; uint32_t drop_thresh; float drop_scale; uint32_t drop_site;
     const uint8_t* drop_mask;         // [B, L, N] keep-mask (DROP_INJECT)
     const RunState* rs;
+    float2* part; long part_rows;     // optional [PART_STRIDE][part_rows] LayerNorm partials of the OUTPUT rows (ln_finalize_k)
     // geometry
     Segs sg;
     int tiles0;                       // number of M tiles of segment 0
@@ -151,7 +169,8 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
     constexpr int ES = WTN + 4;                       // epilogue staging row stride (floats)
     constexpr int BUF_FLOATS = BK * LDA + BK * LDB;
     constexpr int LOOP_FLOATS = NBUF * BUF_FLOATS, EPI_FLOATS = 4 * 32 * ES;
-    constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS ? LOOP_FLOATS : EPI_FLOATS;
+    constexpr int PART_FLOATS = 4 * WTM * 2;          // per-wave (mean, M2) of its WTM rows, written out coalesced
+    constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
     static_assert((BN * 8) % 256 == 0, "every thread stages W");
@@ -355,6 +374,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
         k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
     }
     float* stage = smem + wave * (32 * ES);           // private to this wave: no block barrier needed
+    float2* wpart = reinterpret_cast<float2*>(smem + EPI_FLOATS) + wave * WTM;
     constexpr int LPR = WTN / 4;                      // lanes per staged row (float4 each)
     constexpr int RPI = 64 / LPR;                     // rows per wave instruction
     const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
@@ -406,9 +426,57 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
                 }
                 *reinterpret_cast<f32x4*>(p.C + grow * p.ldc + col) = v;
             }
+            if (p.part) {
+                // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
+                // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
+                // deviations) of its slice with xor-shuffles and ln_finalize_k merges the slices exactly
+                // (Chan et al.), which spares a separate read pass over the activation.
+                const bool valid = lrow < seg_rows && col_ok;
+                const int nv = min(WTN, N - (n0 + wn * WTN));                 // valid columns of this slice (uniform)
+                float ps = valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+                ps = group_sum<LPR>(ps);
+                const float pm = ps / (float)max(nv, 1);
+                float pq = 0.f;
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = v[c] - pm; pq += d * d; }
+                }
+                pq = group_sum<LPR>(pq);
+                if ((lane % LPR) == 0) wpart[32 * i + rr] = make_float2(pm, pq);
+            }
         }
         __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
     }
+    if (p.part) {
+        // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int nv = min(WTN, N - (n0 + wn * WTN));
+        for (int r = lane; r < WTM; r += 64) {
+            const int lrow = m0 + wm * WTM + r;
+            if (lrow < seg_rows && nv > 0)
+                p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge the per-slice (mean, M2) partials a GEMM epilogue left for each output row into (mean, rstd).
+// pw = slice width (the producing kernel's wave-tile width), C = row width.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_finalize_k(const float2* __restrict__ part, int pw, int C, int rows,
+                                                      float2* __restrict__ stats) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int P = (C + pw - 1) / pw;
+    float2 pr[PART_STRIDE];
+    for (int i = 0; i < P; ++i) pr[i] = part[(long)i * rows + row];
+    float mean = 0.f;
+    for (int i = 0; i < P; ++i) mean += pr[i].x * (float)min(pw, C - i * pw);
+    mean /= (float)C;
+    float m2 = 0.f;
+    for (int i = 0; i < P; ++i) { const float d = pr[i].x - mean; m2 += pr[i].y + (float)min(pw, C - i * pw) * d * d; }
+    stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)C + 1e-5f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,14 +508,16 @@ __global__ void __launch_bounds__(256) row_stats_k(const float* __restrict__ X, 
 // Token embedding gather: X[row(b,l), :] = emb[tokens[b,l], :]
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) embed_tokens_k(const int32_t* __restrict__ tokens,
-                                                       const float* __restrict__ emb, int d,
-                                                       float* __restrict__ X, Segs sg) {
+                                                       const float* __restrict__ emb,
+                                                       const float2* __restrict__ emb_stats, int d,
+                                                       float* __restrict__ X, float2* __restrict__ stats, Segs sg) {
     const int bl = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (bl >= sg.B * sg.L) return;
     const int b = bl / sg.L, l = bl - b * sg.L;
     const float* e = emb + (long)tokens[bl] * d;
     float* x = X + (long)sg.row(b, l) * d;
+    if (lane == 0) stats[sg.row(b, l)] = emb_stats[tokens[bl]];    // LayerNorm statistics of an embedding row
     for (int c = lane * 4; c < d; c += 256)
         *reinterpret_cast<f32x4*>(x + c) = *reinterpret_cast<const f32x4*>(e + c);
 }
