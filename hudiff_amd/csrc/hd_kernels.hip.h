@@ -384,6 +384,18 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
     if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        // residual values of this pass are requested up front (each lane reads exactly the elements it will
+        // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
+        // while the accumulators are transposed through LDS instead of serialising load -> store per row
+        f32x4 rres[32 / RPI];
+        if (p.resid) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int lrow = m0 + wm * WTM + 32 * i + it * RPI + e_r;
+                const long grow = (lrow < seg_rows) ? (long)rbase + lrow : (long)rbase;
+                rres[it] = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + (col_ok ? col : 0));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -400,10 +412,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
                 const long grow = (long)rbase + lrow;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
-                if (p.resid) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + col);
-                    v += rv;
-                }
+                if (p.resid) v += rres[it];
                 if (p.drop_mode != DROP_NONE) {
                     const int b = lrow / Lc;
                     const int slot = p.sg.off[seg] + (lrow - b * Lc);
