@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -546,7 +547,13 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     return p;
 }
 
-template <int BM, int BN, int WM, int WN>
+// k-tile depth of the GEMM K loop: 16 by default, HUDIFF_GEMM_BK=32 selects the 32-deep variant (tuning aid)
+static int gemm_bk() {
+    static int bk = [] { const char* e = getenv("HUDIFF_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+    return bk;
+}
+
+template <int BM, int BN, int WM, int WN, int BKT>
 static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     Segs run = p.sg;
     if (!per_seg) {           // weights shared by all rows: treat the whole batch as one segment
@@ -562,7 +569,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     q.tiles_n = (q.N + BN - 1) / BN;
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
     const int pro = q.stats ? 1 + q.pro_act : 0;      // 0 none, 1 LN, 2 LN+ReLU, 3 LN+GELU
-#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO>), grid, blk, 0, st, q)
+#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, 1, BKT>), grid, blk, 0, st, q)
     if (!conv) {
         switch (pro) {
             case 0: HD_LAUNCH(false, 0); break;
@@ -584,8 +591,12 @@ static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float
     const long rows = (long)p.sg.B * p.sg.L;
     const bool big = rows >= 8192;
     p.part_rows = rows;
-    if (big) launch_gemm_t<128, 128, 2, 2>(p, conv, per_seg, st);
-    else launch_gemm_t<32, 128, 1, 4>(p, conv, per_seg, st);
+    if (big) {
+        if (gemm_bk() == 32) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
+        else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
+    } else {
+        launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
+    }
     if (p.part && stats_out)
         hipLaunchKernelGGL(ln_finalize_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows, stats_out);
 }

@@ -158,14 +158,14 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
 //   Epilogue: each wave transposes its accumulators through its own slice of the (now free) LDS so that
 //     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
 //     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
-template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1>
-__global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) {
-    constexpr int BK = 32;
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1, int BK = 32>
+__global__ void __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) gemm_k(const GemmP p) {
+    constexpr int KQ = BK / 4;                        // float4 per A row per k tile
     constexpr int LDA = BM + 1, LDB = BN + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int AIT = (BM * 8 + 255) / 256, BIT = (BN * 8) / 256;
-    constexpr bool A_FULL = (BM * 8) % 256 == 0;      // every thread stages A
+    constexpr int AIT = (BM * KQ + 255) / 256, BIT = (BN * KQ) / 256;
+    constexpr bool A_FULL = (BM * KQ) % 256 == 0;     // every thread stages A
     constexpr int ES = WTN + 4;                       // epilogue staging row stride (floats)
     constexpr int BUF_FLOATS = BK * LDA + BK * LDB;
     constexpr int LOOP_FLOATS = NBUF * BUF_FLOATS, EPI_FLOATS = 4 * 32 * ES;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
     constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-    static_assert((BN * 8) % 256 == 0, "every thread stages W");
+    static_assert((BN * KQ) % 256 == 0, "every thread stages W");
     static_assert((BK * LDA) % 4 == 0, "Bs must stay 16-byte aligned");
 
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
     const int half = (p.taps - 1) / 2;
 
     // per-thread staging coordinates (fixed over the K loop)
-    const int a_kq = tid & 7;                         // k quad within the 32-wide k tile (same for every A row)
+    const int a_kq = tid % KQ;                        // k quad within the k tile (same for every A row of a thread)
     int a_r[AIT], a_pos[AIT];
     bool a_ok[AIT];
     long a_row[AIT];
@@ -217,9 +217,9 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
         const int idx = tid + 256 * i;
-        a_r[i] = idx >> 3;
+        a_r[i] = idx / KQ;
         const int lrow = m0 + a_r[i];
-        a_ok[i] = (A_FULL || idx < BM * 8) && (lrow < seg_rows);
+        a_ok[i] = (A_FULL || idx < BM * KQ) && (lrow < seg_rows);
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;  // clamped: always a readable row
         a_st[i] = make_float2(0.f, 0.f);
@@ -237,10 +237,15 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
     // Loads are unconditional (addresses clamped to something readable) and invalid lanes are zeroed at
     // commit time: no divergent branch or select sits between a load and the MFMAs, so the whole k tile's
     // loads are issued back to back and stay in flight under the MFMAs of the current tile.
+    // CONV: per-tap state (row shift, validity at the chain ends, statistics of the shifted row) changes only
+    // every nkt_tap k tiles, so it is refreshed at tap boundaries instead of every k tile
+    const float* t_ptr[AIT];
+    bool t_ok[AIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) { t_ptr[i] = p.A + a_row[i] * p.lda; t_ok[i] = a_ok[i]; }
     auto fetch = [&](int kt) {
         const int tap = CONV ? kt / nkt_tap : 0;
-        const int kk0 = (CONV ? kt % nkt_tap : kt) * BK;
-        const int shift = CONV ? (tap - half) * p.dil : 0;
+        const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
         const int col = kk0 + 4 * a_kq;
         const bool kv = col < Kc;
         const int colc = kv ? col : 0;
@@ -248,18 +253,22 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
             rg = *reinterpret_cast<const f32x4*>(gamma + colc);
             rb = *reinterpret_cast<const f32x4*>(beta + colc);
         }
+        if (CONV && kk0 == 0) {                        // wave-uniform: first k tile of a tap
+            const int shift = (tap - half) * p.dil;
+#pragma unroll
+            for (int i = 0; i < AIT; ++i) {
+                const int sp = a_pos[i] + shift;
+                const bool v = a_ok[i] && sp >= 0 && sp < Lc;
+                const long srow = v ? a_row[i] + shift : 0;
+                t_ok[i] = v;
+                t_ptr[i] = p.A + srow * p.lda;
+                if (PRO) rst[i] = p.stats[srow];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            bool v = a_ok[i] && kv;
-            long srow = a_row[i];
-            if (CONV) {
-                const int sp = a_pos[i] + shift;
-                v = v && sp >= 0 && sp < Lc;
-                srow = v ? srow + shift : 0;
-            }
-            rav[i] = v;
-            ra[i] = *reinterpret_cast<const f32x4*>(p.A + srow * p.lda + colc);
-            if (PRO && CONV) rst[i] = p.stats[srow];
+            rav[i] = t_ok[i] && kv;
+            ra[i] = *reinterpret_cast<const f32x4*>(t_ptr[i] + colc);
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
@@ -275,7 +284,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) gemm_k(const GemmP p) 
         float (*Bw)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + buf * BUF_FLOATS + BK * LDA);
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            if (A_FULL || tid + 256 * i < BM * 8) {
+            if (A_FULL || tid + 256 * i < BM * KQ) {
                 const float2 st = CONV ? rst[i] : a_st[i];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {

@@ -5,7 +5,7 @@
 #include <vector>
 using namespace hd;
 
-template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABL, int NBUF = 1>
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABL, int NBUF = 1, int BK = 32>
 static float run(GemmP q, int iters) {
     q.tiles0 = (q.sg.B * q.sg.len[0] + BM - 1) / BM;
     q.tiles_m = q.tiles0;
@@ -13,9 +13,9 @@ static float run(GemmP q, int iters) {
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, ABL, NBUF>), grid, blk, 0, 0, q);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, ABL, NBUF, BK>), grid, blk, 0, 0, q);
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, ABL, NBUF>), grid, blk, 0, 0, q);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, ABL, NBUF, BK>), grid, blk, 0, 0, q);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -52,12 +52,12 @@ int main() {
         }
         if (s.taps == 1) {
             float u0 = run<128, 128, 2, 2, false, 0, 0, 2>(p, 5), u1 = run<128, 128, 2, 2, false, 0, 1, 2>(p, 5);
-            float v0 = run<128, 256, 2, 2, false, 0, 0, 2>(p, 5);
-            printf("   2-buffer 128x128: full %7.1f us %6.1f TF no-gload %6.1f TF | 2-buffer 128x256: full %7.1f us %6.1f TF\n",
-                   u0 * 1e3, gf / u0, gf / u1, v0 * 1e3, gf / v0);
+            float v0 = run<128, 128, 2, 2, false, 0, 0, 2, 16>(p, 5), v1 = run<128, 128, 2, 2, false, 0, 0, 1, 16>(p, 5);
+            printf("   2-buffer 128x128: full %7.1f us %6.1f TF no-gload %6.1f TF | BK=16 2-buffer: full %7.1f us %6.1f TF | BK=16 1-buffer %6.1f TF\n",
+                   u0 * 1e3, gf / u0, gf / u1, v0 * 1e3, gf / v0, gf / v1);
         } else {
-            float u0 = run<128, 128, 2, 2, true, 2, 0, 2>(p, 5);
-            printf("   2-buffer 128x128: full %7.1f us %6.1f TF\n", u0 * 1e3, gf / u0);
+            float u0 = run<128, 128, 2, 2, true, 2, 0, 2>(p, 5), v0 = run<128, 128, 2, 2, true, 2, 0, 2, 16>(p, 5);
+            printf("   2-buffer 128x128: full %7.1f us %6.1f TF | BK=16 2-buffer %6.1f TF\n", u0 * 1e3, gf / u0, gf / v0);
         }
         printf("%-22s %7.1f GF | full %7.1f us %6.1f TF | no-gload %7.1f us %6.1f TF | +no-commit/barrier %7.1f us %6.1f TF | mfma-only %7.1f us %6.1f TF\n",
                s.name, gf, t[0] * 1e3, gf / t[0], t[1] * 1e3, gf / t[1], t[2] * 1e3, gf / t[2], t[3] * 1e3, gf / t[3]);
