@@ -159,7 +159,7 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
 //     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
 //     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
 template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1, int BK = 32>
-__global__ void __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) gemm_k(const GemmP p) {
+__global__ void __launch_bounds__(256, (NBUF == 1 && BK == 16) ? 4 : (NBUF == 1 ? 3 : 2)) gemm_k(const GemmP p) {
     constexpr int KQ = BK / 4;                        // float4 per A row per k tile
     constexpr int LDA = BM + 1, LDB = BN + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
