@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="2 = the batch runs as two concurrent half-batches on two streams (library default)")
     return ap.parse_args()
 
 
@@ -126,7 +128,7 @@ def main():
 
     t_up0 = time.perf_counter()
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
-                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph)
+                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph, lanes=args.lanes)
     upload_s = time.perf_counter() - t_up0
     gpu_ms = 0.0
 

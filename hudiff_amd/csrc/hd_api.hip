@@ -104,18 +104,28 @@ struct HdModel {
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     float* side_vec = nullptr;
     float2* emb_stats = nullptr;      // [n_tokens] LayerNorm (mean, rstd) of each embedding row
-    RunState* rs = nullptr;
-    Workspace ws;
+    // Two independent "lanes" (stream + workspace + graph): hd_sample splits a batch into two halves that run
+    // concurrently on their own streams.  Rows are independent, so there is no cross-lane dependency; one lane's
+    // kernel tails / attention staging / launch gaps are filled by the other lane's kernels.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        RunState* rs = nullptr;
+        Workspace ws;
+        int B = 0, row_off = 0;                      // rows of the open session handled by this lane
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t graph_exec = nullptr;
+        int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
+        int graph_qB = -1, graph_qoff = -1;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } lane[2];
+    int cl = 0;                                      // lane the helper functions currently address
+    int nlanes = 1;
     // sampling session
     bool in_session = false;
     int sB = 0, sTmax = 0;
     uint64_t s_row0 = 0;
     uint32_t sflags = 0;
     bool s_has_q = false;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_steps = 0; bool timed = false;
     int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
 };
@@ -201,10 +211,12 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
     m->A = c.att_model; m->Fd = c.dim_feedforward; m->L = c.max_len;
     m->p_enc = c.dropout;
     m->p_conv = c.dropout > 0.f ? 0.5f : 0.f;   // F.dropout(x) default p, gated by cfg.dropout > 0 (model.py:295-303)
-    hipError_t e = hipStreamCreate(&m->stream);
-    if (e != hipSuccess) { delete m; return fail(HD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    hipEventCreate(&m->ev0);
-    hipEventCreate(&m->ev1);
+    for (auto& ln : m->lane) {
+        hipError_t e = hipStreamCreate(&ln.stream);
+        if (e != hipSuccess) { delete m; return fail(HD_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        hipEventCreate(&ln.ev0);
+        hipEventCreate(&ln.ev1);
+    }
     *out = m;
     return HD_OK;
 }
@@ -217,17 +229,19 @@ static void free_ws(Workspace& ws) {
 extern "C" void hd_destroy(HdModel* m) {
     if (!m) return;
     hipSetDevice(m->device);
-    if (m->stream) hipStreamSynchronize(m->stream);
-    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) hipGraphDestroy(m->graph);
-    free_ws(m->ws);
+    for (auto& ln : m->lane) {
+        if (ln.stream) hipStreamSynchronize(ln.stream);
+        if (ln.graph_exec) hipGraphExecDestroy(ln.graph_exec);
+        if (ln.graph) hipGraphDestroy(ln.graph);
+        free_ws(ln.ws);
+        if (ln.rs) hipFree(ln.rs);
+        if (ln.ev0) hipEventDestroy(ln.ev0);
+        if (ln.ev1) hipEventDestroy(ln.ev1);
+        if (ln.stream) hipStreamDestroy(ln.stream);
+    }
     if (m->blob) hipFree(m->blob);
     if (m->side_vec) hipFree(m->side_vec);
     if (m->emb_stats) hipFree(m->emb_stats);
-    if (m->rs) hipFree(m->rs);
-    if (m->ev0) hipEventDestroy(m->ev0);
-    if (m->ev1) hipEventDestroy(m->ev1);
-    if (m->stream) hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -476,19 +490,22 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     if (ab) m->sidew = {B0 + s_emb, B0 + s_w1, B0 + s_b1, B0 + s_lg, B0 + s_lb, B0 + s_w2, B0 + s_b2};
     m->head = {B0 + h_g, B0 + h_b, B0 + h_w, B0 + h_bias};
     m->rope_cos = B0 + o_cos; m->rope_sin = B0 + o_sin;
-    HIP_TRY(hipMalloc(&m->rs, sizeof(RunState)));
-    HIP_TRY(hipMemset(m->rs, 0, sizeof(RunState)));
+    for (auto& ln : m->lane) {
+        HIP_TRY(hipMalloc(&ln.rs, sizeof(RunState)));
+        HIP_TRY(hipMemset(ln.rs, 0, sizeof(RunState)));
+    }
+    m->cl = 0;
     HIP_TRY(hipMalloc(&m->emb_stats, sizeof(float2) * c.n_tokens));
-    hipLaunchKernelGGL(row_stats_k, dim3((c.n_tokens + 3) / 4), dim3(256), 0, m->stream, m->emb, d, d, c.n_tokens, m->emb_stats);
+    hipLaunchKernelGGL(row_stats_k, dim3((c.n_tokens + 3) / 4), dim3(256), 0, m->lane[m->cl].stream, m->emb, d, d, c.n_tokens, m->emb_stats);
     if (ab) {
         HIP_TRY(hipMalloc(&m->side_vec, sizeof(float) * c.n_side * d));
-        hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, m->stream, m->sidew, se, d, m->side_vec);
+        hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, m->lane[m->cl].stream, m->sidew, se, d, m->side_vec);
         HIP_TRY(hipGetLastError());
     }
     const size_t smem = (size_t)L * (ATT_KS + ATT_VS) * sizeof(float);
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
     m->host.clear();
     m->finalized = true;
     return HD_OK;
@@ -505,12 +522,12 @@ static HdStatus dalloc(Workspace& ws, T** p, size_t n) {
 }
 
 static HdStatus ensure_ws(HdModel* m, int B) {
-    Workspace& ws = m->ws;
+    Workspace& ws = m->lane[m->cl].ws;
     if (B <= ws.capB) return HD_OK;
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
-    m->graph_B = -1;
+    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
+    if (m->lane[m->cl].graph_exec) { hipGraphExecDestroy(m->lane[m->cl].graph_exec); m->lane[m->cl].graph_exec = nullptr; }
+    if (m->lane[m->cl].graph) { hipGraphDestroy(m->lane[m->cl].graph); m->lane[m->cl].graph = nullptr; }
+    m->lane[m->cl].graph_B = -1;
     free_ws(ws);
     const size_t M = (size_t)B * m->L;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, A = m->A, Fd = m->Fd;
@@ -543,7 +560,7 @@ struct Drop { int mode = DROP_NONE; float p = 0.f; uint32_t site = 0; const uint
 
 static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     GemmP p{};
-    p.sg = sg; p.taps = 1; p.dil = 1; p.rs = m->rs;
+    p.sg = sg; p.taps = 1; p.dil = 1; p.rs = m->lane[m->cl].rs;
     return p;
 }
 
@@ -602,7 +619,7 @@ static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float
 }
 
 static void launch_stats(const HdModel* m, const float* X, int ldx, int C, int rows, hipStream_t st) {
-    hipLaunchKernelGGL(row_stats_k, dim3((rows + 3) / 4), dim3(256), 0, st, X, ldx, C, rows, m->ws.ST);
+    hipLaunchKernelGGL(row_stats_k, dim3((rows + 3) / 4), dim3(256), 0, st, X, ldx, C, rows, m->lane[m->cl].ws.ST);
 }
 
 static void set_drop(GemmP& p, const Drop& dr) {
@@ -622,57 +639,57 @@ static void set_drop(GemmP& p, const Drop& dr) {
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
                           const Drop& dr, const float* extra, int lde, bool x_stats_ready, bool want_out_stats) {
-    hipStream_t st = m->stream;
+    hipStream_t st = m->lane[m->cl].stream;
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
     if (!x_stats_ready) launch_stats(m, x, ldx, din, rows, st);
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
-    p.stats = m->ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = m->ws.PART;
-    launch_gemm(p, false, true, st, m->ws.ST);
+    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = m->lane[m->cl].ws.PART;
+    launch_gemm(p, false, true, st, m->lane[m->cl].ws.ST);
 
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    p.stats = m->ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act; p.part = m->ws.PART;
-    launch_gemm(p, true, true, st, m->ws.ST);
+    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act; p.part = m->lane[m->cl].ws.PART;
+    launch_gemm(p, true, true, st, m->lane[m->cl].ws.ST);
 
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
-    p.stats = m->ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     set_drop(p, dr);
-    if (want_out_stats) p.part = m->ws.PART;
-    launch_gemm(p, false, true, st, m->ws.ST);
+    if (want_out_stats) p.part = m->lane[m->cl].ws.PART;
+    launch_gemm(p, false, true, st, m->lane[m->cl].ws.ST);
 }
 
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
                             const float* g, const float* b, const float* resid, float* out, bool want_out_stats) {
-    hipStream_t st = m->stream;
+    hipStream_t st = m->lane[m->cl].stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
-    p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = m->ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
-    if (ln) { p.stats = m->ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
+    p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = m->lane[m->cl].ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
+    if (ln) { p.stats = m->lane[m->cl].ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
     launch_gemm(p, false, false, st);
     const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
     if (m->L > 160)
-        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, m->lane[m->cl].ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->lane[m->cl].ws.O, A, m->cfg.nhead, sg);
     else
-        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, m->ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, m->lane[m->cl].ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->lane[m->cl].ws.O, A, m->cfg.nhead, sg);
     p = base_gemm(m, sg);
-    p.A = m->ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
+    p.A = m->lane[m->cl].ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    if (want_out_stats) p.part = m->ws.PART;
-    launch_gemm(p, false, false, st, m->ws.ST);
+    if (want_out_stats) p.part = m->lane[m->cl].ws.PART;
+    launch_gemm(p, false, false, st, m->lane[m->cl].ws.ST);
 }
 
 // The token-independent branch (RegionEmbedder, PosEmbedder, SideEmbedder): once per batch.
 static HdStatus static_branch(HdModel* m, const Segs& sg) {
-    hipStream_t st = m->stream;
-    Workspace& ws = m->ws;
+    hipStream_t st = m->lane[m->cl].stream;
+    Workspace& ws = m->lane[m->cl].ws;
     const int d = m->d, D = m->D, rows = sg.rows();
     hipLaunchKernelGGL(region_embed_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.region, m->regw, m->cfg.r_embedding, d, ws.POS, sg);
     // pos = x + W2 gelu(W1 x + b1) + b2      (MLP model.py:28-33; nn.Dropout is inactive in eval mode)
@@ -692,8 +709,8 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
 // Last SelfAttBlock of a sampling step, from "at = x + A1(x)" (in ws.AT, statistics in ws.ST) on, evaluated only
 // for the row each sequence visits at this step (see gather_rows_k).  Result: ws.Xc [B, D] = block output rows.
 static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
-    hipStream_t st = m->stream;
-    Workspace& ws = m->ws;
+    hipStream_t st = m->lane[m->cl].stream;
+    Workspace& ws = m->lane[m->cl].ws;
     const int D = m->D, A = m->A, Fd = m->Fd, B = sg.B;
     Segs cs{};                      // compact [B, *] matrices: one "sequence" of B single-slot rows
     cs.nseg = 1; cs.B = B; cs.L = 1; cs.len[0] = 1;
@@ -703,8 +720,8 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.N = 2 * A; p.Kc = D; p.stats = ws.ST; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
     launch_gemm(p, false, false, st);
     // visited rows of `at` and of the block input x
-    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, m->rs, sg);
-    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, m->rs, sg);
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
     hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
     // q = LN1(at_c) Wq + bq
     p = base_gemm(m, cs);
@@ -712,7 +729,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.stats = ws.STc; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
     launch_gemm(p, false, false, st);
     hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
-                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, m->rs, sg);
+                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
     // at_c = at_c + o Wo + bo
     p = base_gemm(m, cs);
     p.A = ws.Oc; p.lda = A; p.W = w.a2.wo; p.bias = w.a2.bo; p.C = ws.ATc; p.ldc = D; p.N = D; p.Kc = A; p.resid = ws.ATc; p.ldr = D;
@@ -731,8 +748,8 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
 // One denoiser forward up to the last attention block; result rows in ws.Y.
 static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks,
                              bool prune_last = false) {
-    hipStream_t st = m->stream;
-    Workspace& ws = m->ws;
+    hipStream_t st = m->lane[m->cl].stream;
+    Workspace& ws = m->lane[m->cl].ws;
     const HdConfig& c = m->cfg;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
     hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
@@ -791,19 +808,19 @@ static HdStatus validate_inputs(const HdModel* m, const int32_t* tokens, const i
 }
 
 static HdStatus upload_common(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain, int B) {
-    Workspace& ws = m->ws;
+    Workspace& ws = m->lane[m->cl].ws;
     const size_t M = (size_t)B * m->L;
-    HIP_TRY(hipMemcpyAsync(ws.tokens, tokens, M * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(ws.region, region, M * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-    if (m->nseg > 1) HIP_TRY(hipMemcpyAsync(ws.chain, chain, (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(ws.tokens, tokens, M * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
+    HIP_TRY(hipMemcpyAsync(ws.region, region, M * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
+    if (m->nseg > 1) HIP_TRY(hipMemcpyAsync(ws.chain, chain, (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
     return HD_OK;
 }
 
 static HdStatus set_run_state(HdModel* m, uint64_t seed, uint64_t row0, uint32_t step) {
     RunState h{};
     h.step = step; h.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu); h.seed_hi = (uint32_t)(seed >> 32); h.row0 = (uint32_t)row0;
-    HIP_TRY(hipMemcpyAsync(m->rs, &h, sizeof(h), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));   // h is a stack object
+    HIP_TRY(hipMemcpyAsync(m->lane[m->cl].rs, &h, sizeof(h), hipMemcpyHostToDevice, m->lane[m->cl].stream));
+    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));   // h is a stack object
     return HD_OK;
 }
 
@@ -817,7 +834,7 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 template <typename T>
 static HdStatus ensure_buf(HdModel* m, T** p, size_t* cap, size_t n) {
     if (n <= *cap) return HD_OK;
-    HD_TRY(dalloc(m->ws, p, n));
+    HD_TRY(dalloc(m->lane[m->cl].ws, p, n));
     *cap = n;
     return HD_OK;
 }
@@ -831,11 +848,12 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
     if (B < 0) return fail(HD_ERR_INVALID, "hd_forward: B = %d", B);
     if (B == 0) return HD_OK;
     HIP_TRY(hipSetDevice(m->device));
+    m->cl = 0;
     HD_TRY(validate_inputs(m, tokens, region, chain, B));
     const int dm = drop_mode_of(m, flags);
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_forward: HD_DROPOUT_INJECT needs enc_masks and conv_masks");
     HD_TRY(ensure_ws(m, B));
-    Workspace& ws = m->ws;
+    Workspace& ws = m->lane[m->cl].ws;
     const Segs sg = make_segs(m, B);
     HD_TRY(upload_common(m, tokens, region, chain, B));
     HD_TRY(set_run_state(m, seed, row0, step));
@@ -844,28 +862,30 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
         const size_t ne = (size_t)m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)m->cfg.dual_layers * B * m->L * m->D;
         HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
         HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
-        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->lane[m->cl].stream));
+        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->lane[m->cl].stream));
         dem = ws.enc_masks; dcm = ws.conv_masks;
     }
     HD_TRY(static_branch(m, sg));
     HD_TRY(forward_body(m, sg, dm, dem, dcm));
     const int rows = sg.rows();
-    hipLaunchKernelGGL(decode_all_k, dim3((rows + 3) / 4), dim3(256), 0, m->stream, ws.Y, m->D, m->head, m->cfg.n_tokens, ws.LOGITS, sg);
+    hipLaunchKernelGGL(decode_all_k, dim3((rows + 3) / 4), dim3(256), 0, m->lane[m->cl].stream, ws.Y, m->D, m->head, m->cfg.n_tokens, ws.LOGITS, sg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, m->lane[m->cl].stream));
+    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
     return HD_OK;
 }
 
 // ---- sampling session ---------------------------------------------------------------------------
 static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, const uint8_t* cm) {
+    HdModel::Lane& ln = m->lane[m->cl];
     const bool prune = !(m->sflags & HD_NO_PRUNE);
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
-    Workspace& ws = m->ws;
-    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, m->stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
-                       ws.T, m->sTmax, m->s_has_q ? ws.qnoise : nullptr, m->rs, sg, prune ? 1 : 0);
-    hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, m->stream, m->rs);
+    Workspace& ws = ln.ws;
+    // the injected Exp(1) noise lives once, for the whole batch, in lane 0's workspace
+    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
+                       ws.T, m->sTmax, m->s_has_q ? m->lane[0].ws.qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0);
+    hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }
@@ -880,6 +900,7 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
     if (B < 0 || Tmax < 0) return fail(HD_ERR_INVALID, "hd_sample_begin: B = %d, Tmax = %d", B, Tmax);
     HIP_TRY(hipSetDevice(m->device));
     m->sB = B; m->sTmax = Tmax; m->sflags = flags; m->s_has_q = q_noise != nullptr; m->timed = false; m->last_steps = 0;
+    m->nlanes = 1; m->cl = 0;
     if (B == 0) { m->in_session = true; return HD_OK; }
     HD_TRY(validate_inputs(m, tokens, region, chain, B));
     for (int b = 0; b < B; ++b) {
@@ -891,33 +912,52 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
     }
     const int dm = drop_mode_of(m, flags);
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_sample_begin: HD_DROPOUT_INJECT needs masks");
-    HD_TRY(ensure_ws(m, B));
-    Workspace& ws = m->ws;
-    const Segs sg = make_segs(m, B);
-    HD_TRY(upload_common(m, tokens, region, chain, B));
-    {
-        size_t cap = (size_t)ws.capT;
-        size_t need = (size_t)B * (Tmax > 0 ? Tmax : 1);
-        if (need > cap) { HD_TRY(dalloc(ws, &ws.order, need)); ws.capT = (int)need; }
+    // two concurrent half-batches unless the batch is small, masks are injected (their layout is per full batch)
+    // or the caller asked for one lane
+    m->nlanes = (B >= 64 && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? 2 : 1;
+    const int B0 = m->nlanes == 2 ? (B + 1) / 2 : B;
+    m->lane[0].B = B0; m->lane[0].row_off = 0;
+    m->lane[1].B = B - B0; m->lane[1].row_off = B0;
+    std::vector<int32_t> chain_l;
+    for (int l = 0; l < m->nlanes; ++l) {
+        m->cl = l;
+        HdModel::Lane& ln = m->lane[l];
+        const int Bl = ln.B, off = ln.row_off;
+        HD_TRY(ensure_ws(m, Bl));
+        Workspace& ws = ln.ws;
+        const Segs sg = make_segs(m, Bl);
+        const int32_t* ch = nullptr;
+        if (m->nseg > 1) {            // chain[0:B] heavy ids, chain[B:2B] light ids -> this lane's [heavy | light]
+            chain_l.assign((size_t)2 * Bl, 0);
+            for (int b = 0; b < Bl; ++b) { chain_l[b] = chain[off + b]; chain_l[Bl + b] = chain[B + off + b]; }
+            ch = chain_l.data();
+        }
+        HD_TRY(upload_common(m, tokens + (size_t)off * m->L, region + (size_t)off * m->L, ch, Bl));
+        HIP_TRY(hipStreamSynchronize(ln.stream));          // chain_l is reused by the next lane
+        {
+            const size_t need = (size_t)Bl * (Tmax > 0 ? Tmax : 1);
+            if (need > (size_t)ws.capT) { HD_TRY(dalloc(ws, &ws.order, need)); ws.capT = (int)need; }
+        }
+        if (Tmax > 0) HIP_TRY(hipMemcpyAsync(ws.order, order + (size_t)off * Tmax, (size_t)Bl * Tmax * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
+        HIP_TRY(hipMemcpyAsync(ws.T, T + off, (size_t)Bl * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
+        if (l == 0 && q_noise && Tmax > 0) {
+            const size_t n = (size_t)Tmax * B * 22;
+            HD_TRY(ensure_buf(m, &ws.qnoise, &ws.qnoise_cap, n));
+            HIP_TRY(hipMemcpyAsync(ws.qnoise, q_noise, n * sizeof(float), hipMemcpyHostToDevice, ln.stream));
+        }
+        if (dm == DROP_INJECT && Tmax > 0) {
+            const size_t ne = (size_t)Tmax * m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)Tmax * m->cfg.dual_layers * B * m->L * m->D;
+            HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
+            HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
+            HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, ln.stream));
+            HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, ln.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(ws.tokens0, ws.tokens, (size_t)Bl * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, ln.stream));
+        HD_TRY(set_run_state(m, seed, row0 + (uint64_t)off, 0));
+        HD_TRY(static_branch(m, sg));
     }
-    if (Tmax > 0) HIP_TRY(hipMemcpyAsync(ws.order, order, (size_t)B * Tmax * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(ws.T, T, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-    if (q_noise && Tmax > 0) {
-        const size_t n = (size_t)Tmax * B * 22;
-        HD_TRY(ensure_buf(m, &ws.qnoise, &ws.qnoise_cap, n));
-        HIP_TRY(hipMemcpyAsync(ws.qnoise, q_noise, n * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    }
-    if (dm == DROP_INJECT && Tmax > 0) {
-        const size_t ne = (size_t)Tmax * m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)Tmax * m->cfg.dual_layers * B * m->L * m->D;
-        HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
-        HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
-        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(ws.tokens0, ws.tokens, (size_t)B * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
-    HD_TRY(set_run_state(m, seed, row0, 0));
-    HD_TRY(static_branch(m, sg));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
+    m->cl = 0;
     m->s_row0 = row0;
     m->in_session = true;
     return HD_OK;
@@ -927,8 +967,13 @@ extern "C" HdStatus hd_sample_restart(HdModel* m, uint64_t seed) {
     if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_restart: no open session");
     if (m->sB == 0) return HD_OK;
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemcpyAsync(m->ws.tokens, m->ws.tokens0, (size_t)m->sB * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
-    HD_TRY(set_run_state(m, seed, m->s_row0, 0));
+    for (int l = 0; l < m->nlanes; ++l) {
+        m->cl = l;
+        HdModel::Lane& ln = m->lane[l];
+        HIP_TRY(hipMemcpyAsync(ln.ws.tokens, ln.ws.tokens0, (size_t)ln.B * m->L * sizeof(int32_t), hipMemcpyDeviceToDevice, ln.stream));
+        HD_TRY(set_run_state(m, seed, m->s_row0 + (uint64_t)ln.row_off, 0));
+    }
+    m->cl = 0;
     return HD_OK;
 }
 
@@ -937,35 +982,48 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
     if (t0 < 0 || t1 < t0 || t1 > m->sTmax) return fail(HD_ERR_INVALID, "hd_sample_run: steps [%d,%d) outside [0,%d]", t0, t1, m->sTmax);
     if (m->sB == 0 || t1 == t0) return HD_OK;
     HIP_TRY(hipSetDevice(m->device));
-    const Segs sg = make_segs(m, m->sB);
     const int dm = drop_mode_of(m, m->sflags);
-    Workspace& ws = m->ws;
-    hipLaunchKernelGGL(set_step_k, dim3(1), dim3(1), 0, m->stream, m->rs, (uint32_t)t0);
     const bool use_graph = !(m->sflags & HD_NO_GRAPH) && dm != DROP_INJECT;
-    if (use_graph) {
-        if (!m->graph_exec || m->graph_B != m->sB || m->graph_flags != (m->sflags & HD_NO_PRUNE) || m->graph_drop != dm || m->graph_q != m->s_has_q || m->graph_Tmax != m->sTmax) {
-            if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-            if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    for (int l = 0; l < m->nlanes; ++l) {
+        m->cl = l;
+        HdModel::Lane& ln = m->lane[l];
+        const Segs sg = make_segs(m, ln.B);
+        hipLaunchKernelGGL(set_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs, (uint32_t)t0);
+        if (!use_graph) continue;
+        const uint32_t gflags = m->sflags & HD_NO_PRUNE;
+        if (!ln.graph_exec || ln.graph_B != ln.B || ln.graph_flags != gflags || ln.graph_drop != dm || ln.graph_q != m->s_has_q ||
+            ln.graph_Tmax != m->sTmax || ln.graph_qB != m->sB || ln.graph_qoff != ln.row_off) {
+            if (ln.graph_exec) { hipGraphExecDestroy(ln.graph_exec); ln.graph_exec = nullptr; }
+            if (ln.graph) { hipGraphDestroy(ln.graph); ln.graph = nullptr; }
+            HIP_TRY(hipStreamSynchronize(ln.stream));
+            HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
             HdStatus s = one_step(m, sg, dm, nullptr, nullptr);
-            hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
-            if (s != HD_OK) return s;
-            if (e != hipSuccess) return fail(HD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIP_TRY(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-            m->graph_B = m->sB; m->graph_flags = (m->sflags & HD_NO_PRUNE); m->graph_drop = dm; m->graph_q = m->s_has_q; m->graph_Tmax = m->sTmax;
+            hipError_t e = hipStreamEndCapture(ln.stream, &ln.graph);
+            if (s != HD_OK) { m->cl = 0; return s; }
+            if (e != hipSuccess) { m->cl = 0; return fail(HD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+            HIP_TRY(hipGraphInstantiate(&ln.graph_exec, ln.graph, nullptr, nullptr, 0));
+            ln.graph_B = ln.B; ln.graph_flags = gflags; ln.graph_drop = dm; ln.graph_q = m->s_has_q; ln.graph_Tmax = m->sTmax;
+            ln.graph_qB = m->sB; ln.graph_qoff = ln.row_off;
         }
-        HIP_TRY(hipEventRecord(m->ev0, m->stream));
-        for (int t = t0; t < t1; ++t) HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
-        HIP_TRY(hipEventRecord(m->ev1, m->stream));
-    } else {
-        const size_t es = (size_t)m->cfg.n_encoder_layers * m->sB * m->L * m->d, cs = (size_t)m->cfg.dual_layers * m->sB * m->L * m->D;
-        HIP_TRY(hipEventRecord(m->ev0, m->stream));
-        for (int t = t0; t < t1; ++t)
-            HD_TRY(one_step(m, sg, dm, dm == DROP_INJECT ? ws.enc_masks + (size_t)t * es : nullptr,
-                            dm == DROP_INJECT ? ws.conv_masks + (size_t)t * cs : nullptr));
-        HIP_TRY(hipEventRecord(m->ev1, m->stream));
     }
+    for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipEventRecord(m->lane[l].ev0, m->lane[l].stream));
+    if (use_graph) {
+        // the lanes are fed alternately; on the device they run concurrently and drift freely (no cross-lane edges)
+        for (int t = t0; t < t1; ++t)
+            for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipGraphLaunch(m->lane[l].graph_exec, m->lane[l].stream));
+    } else {
+        for (int t = t0; t < t1; ++t)
+            for (int l = 0; l < m->nlanes; ++l) {
+                m->cl = l;
+                HdModel::Lane& ln = m->lane[l];
+                const Segs sg = make_segs(m, ln.B);
+                const size_t es = (size_t)m->cfg.n_encoder_layers * ln.B * m->L * m->d, cs = (size_t)m->cfg.dual_layers * ln.B * m->L * m->D;
+                HD_TRY(one_step(m, sg, dm, dm == DROP_INJECT ? ln.ws.enc_masks + (size_t)t * es : nullptr,
+                                dm == DROP_INJECT ? ln.ws.conv_masks + (size_t)t * cs : nullptr));
+            }
+    }
+    for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipEventRecord(m->lane[l].ev1, m->lane[l].stream));
+    m->cl = 0;
     m->timed = true;
     m->last_steps = t1 - t0;
     return HD_OK;
@@ -974,7 +1032,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
 extern "C" HdStatus hd_sync(HdModel* m) {
     if (!m) return fail(HD_ERR_INVALID, "hd_sync: null model");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (auto& ln : m->lane) HIP_TRY(hipStreamSynchronize(ln.stream));
     return HD_OK;
 }
 
@@ -984,8 +1042,12 @@ extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
     if (m->sB == 0) return HD_OK;
     if (!tokens) return fail(HD_ERR_INVALID, "hd_sample_end: null tokens");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemcpyAsync(tokens, m->ws.tokens, (size_t)m->sB * m->L * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int l = 0; l < m->nlanes; ++l) {
+        HdModel::Lane& ln = m->lane[l];
+        HIP_TRY(hipMemcpyAsync(tokens + (size_t)ln.row_off * m->L, ln.ws.tokens, (size_t)ln.B * m->L * sizeof(int32_t), hipMemcpyDeviceToHost, ln.stream));
+    }
+    for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
+    m->cl = 0;
     return HD_OK;
 }
 
@@ -997,7 +1059,7 @@ extern "C" HdStatus hd_sample(HdModel* m, int32_t* tokens, const int32_t* region
     int tmax_eff = 0;
     for (int b = 0; b < B; ++b) tmax_eff = T[b] > tmax_eff ? T[b] : tmax_eff;
     HdStatus s = hd_sample_run(m, 0, tmax_eff);
-    if (s != HD_OK) { m->in_session = false; return s; }
+    if (s != HD_OK) { m->in_session = false; m->cl = 0; return s; }
     return hd_sample_end(m, tokens);
 }
 
@@ -1005,8 +1067,14 @@ extern "C" HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps) {
     if (!m || !ms) return fail(HD_ERR_INVALID, "hd_last_run_ms: null argument");
     if (!m->timed) return fail(HD_ERR_STATE, "hd_last_run_ms: no timed run");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipEventSynchronize(m->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
+    float best = 0.f;
+    for (int l = 0; l < m->nlanes; ++l) {       // from the first lane's start event to the last lane's end event
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(m->lane[l].ev1));
+        HIP_TRY(hipEventElapsedTime(&t, m->lane[0].ev0, m->lane[l].ev1));
+        best = t > best ? t : best;
+    }
+    *ms = best;
     if (steps) *steps = m->last_steps;
     return HD_OK;
 }
@@ -1021,7 +1089,7 @@ extern "C" HdStatus hd_debug_stop_after(HdModel* m, int32_t stage) {
 extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats) {
     if (!m || !name || !out) return fail(HD_ERR_INVALID, "hd_debug_read: null argument");
     HIP_TRY(hipSetDevice(m->device));
-    const Workspace& ws = m->ws;
+    const Workspace& ws = m->lane[m->cl].ws;
     const std::string k(name);
     const float* src = nullptr;
     int width = 0;
@@ -1035,7 +1103,7 @@ extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float
     if (B > ws.capB || n_floats != (int64_t)B * m->L * width) return fail(HD_ERR_INVALID, "hd_debug_read: size mismatch");
     // rows are segment-major on the device; return them as [B, L, width]
     std::vector<float> tmp((size_t)n_floats);
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
     HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
     const Segs sg = make_segs(m, B);
     for (int b = 0; b < B; ++b)

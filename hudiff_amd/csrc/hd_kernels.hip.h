@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm
                                                      int32_t* __restrict__ tokens,
                                                      const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ T, int Tmax,
-                                                     const float* __restrict__ q_noise,
+                                                     const float* __restrict__ q_noise, int q_rows, int q_off,
                                                      const RunState* __restrict__ rs, Segs sg, int compact) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const uint32_t t = rs->step;
@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm
     float q = 1.f;
     if (lane < 22) {
         if (q_noise) {
-            q = q_noise[((long)t * sg.B + b) * 22 + lane];
+            q = q_noise[((long)t * q_rows + q_off + b) * 22 + lane];     // [Tmax, rows of the whole batch, 22]
         } else {
             uint32_t o[4];
             philox4x32_10((uint32_t)lane >> 2, rs->row0 + (uint32_t)b, t, 0xFFFFFFFFU, rs->seed_lo, rs->seed_hi, o);

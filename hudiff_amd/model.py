@@ -164,9 +164,9 @@ class _Denoiser:
         return tok, reg, chn, B, was_torch
 
     @staticmethod
-    def _flags(dropout, graph=True, prune=True):
+    def _flags(dropout, graph=True, prune=True, lanes=2):
         f = {"faithful": L.HD_DROPOUT_FAITHFUL, "off": L.HD_DROPOUT_OFF, "inject": L.HD_DROPOUT_INJECT}[dropout]
-        return f | (0 if graph else L.HD_NO_GRAPH) | (0 if prune else L.HD_NO_PRUNE)
+        return f | (0 if graph else L.HD_NO_GRAPH) | (0 if prune else L.HD_NO_PRUNE) | (0 if lanes == 2 else L.HD_ONE_LANE)
 
     def forward(self, H_L_seq, H_L_region_type, H_L_chn_type=None, *, dropout="faithful", seed=0, row0=0,
                 step=0, enc_masks=None, conv_masks=None):
@@ -201,14 +201,14 @@ class _Denoiser:
         return tok, reg, chn, order, T, B, Tmax, q, em, cm, was_torch
 
     def sample(self, tokens, region, chain, order, T, *, seed=0, row0=0, q_noise=None, dropout="faithful",
-               enc_masks=None, conv_masks=None, graph=True, prune=True):
+               enc_masks=None, conv_masks=None, graph=True, prune=True, lanes=2):
         """Run the T-step loop (sample.py:499-513) for B independent rows; returns the filled tokens."""
         tok, reg, chn, order, T, B, Tmax, q, em, cm, was_torch = self._sample_args(
             tokens, region, chain, order, T, q_noise, enc_masks, conv_masks)
         out = tok.copy()
         L.check(self._lib.hd_sample(self._h, L.ptr(out, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
                                     L.ptr(order, C.c_int32), L.ptr(T, C.c_int32), B, Tmax,
-                                    self._flags(dropout, graph, prune), int(seed), int(row0), L.ptr(q, C.c_float),
+                                    self._flags(dropout, graph, prune, lanes), int(seed), int(row0), L.ptr(q, C.c_float),
                                     L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8)))
         if was_torch:
             import torch
@@ -216,12 +216,12 @@ class _Denoiser:
         return out
 
     def sample_begin(self, tokens, region, chain, order, T, *, seed=0, row0=0, q_noise=None, dropout="faithful",
-                     enc_masks=None, conv_masks=None, graph=True, prune=True):
+                     enc_masks=None, conv_masks=None, graph=True, prune=True, lanes=2):
         tok, reg, chn, order, T, B, Tmax, q, em, cm, _ = self._sample_args(
             tokens, region, chain, order, T, q_noise, enc_masks, conv_masks)
         L.check(self._lib.hd_sample_begin(self._h, L.ptr(tok, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
                                           L.ptr(order, C.c_int32), L.ptr(T, C.c_int32), B, Tmax,
-                                          self._flags(dropout, graph, prune), int(seed), int(row0), L.ptr(q, C.c_float),
+                                          self._flags(dropout, graph, prune, lanes), int(seed), int(row0), L.ptr(q, C.c_float),
                                           L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8)))
         self._session_B = B
 

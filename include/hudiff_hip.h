@@ -68,8 +68,10 @@ enum {
     HD_DROPOUT_INJECT   = 2u,  /* caller supplies keep-masks (parity tests)                         */
     HD_DROPOUT_MASK     = 3u,
     HD_NO_GRAPH         = 4u,  /* launch kernels eagerly instead of replaying the captured hipGraph */
-    HD_NO_PRUNE         = 8u   /* hd_sample: evaluate the last attention block for every row (as hd_forward
+    HD_NO_PRUNE         = 8u,  /* hd_sample: evaluate the last attention block for every row (as hd_forward
                                   does) instead of only for the row each sequence visits at that step      */
+    HD_ONE_LANE         = 16u  /* hd_sample: keep the batch on one stream (default: batches >= 64 rows are
+                                  split into two halves that run concurrently on two streams)              */
 };
 
 /* Hyper-parameters: the `model:` section of configs/antibody_train.yml:3-24 / heavy_train.yml:3-21,

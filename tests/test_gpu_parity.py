@@ -91,6 +91,27 @@ def test_pruned_last_block_equals_full_evaluation(micro):
     assert np.array_equal(a, b)
 
 
+def test_two_lanes_equal_one_lane(micro):
+    """Batches of >= 64 rows run as two concurrent half-batches on two streams; results must not change."""
+    from hudiff_amd import synthetic as S
+    B = 71
+    batch = S.synthetic_batch(micro["kind"], B, seed=33)
+    T = np.minimum(batch["T"], 9); T[5] = 0; T[40] = 4
+    kw = dict(seed=123456789, row0=1000, dropout="faithful")
+    one = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, lanes=1, **kw)
+    two = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, lanes=2, **kw)
+    assert np.array_equal(one, two)
+    # injected Exp(1) noise is indexed by the row of the WHOLE batch in both lanes
+    q = np.random.default_rng(0).exponential(size=(batch["order"].shape[1], B, 22)).astype(np.float32)
+    one = micro["m0"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, lanes=1, q_noise=q)
+    two = micro["m0"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, lanes=2, q_noise=q)
+    assert np.array_equal(one, two)
+    want = ho.sample(micro["o0"], batch["tokens"][36:40], batch["region"][36:40],
+                     None if batch["chain"] is None else np.concatenate([batch["chain"][36:40], batch["chain"][B + 36:B + 40]]),
+                     batch["order"][36:40], T[36:40], q_noise=q[:, 36:40])
+    assert np.array_equal(two[36:40], want)          # rows of the second lane against the oracle
+
+
 def test_sampling_with_reference_dropout_masks(micro):
     z = load_golden(f"micro_{micro['kind']}_sample_dropout.npz")
     B, loc = z["tokens"].shape[0], z["loc"]
