@@ -83,6 +83,12 @@ struct Workspace {
     std::vector<void*> owned;
 };
 
+constexpr int HD_MAX_LANES = 4;
+static int lanes_default() {
+    static int n = [] { const char* e = getenv("HUDIFF_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > HD_MAX_LANES ? HD_MAX_LANES : v); }();
+    return n;
+}
+
 struct HdModel {
     HdConfig cfg{};
     int device = 0;
@@ -117,7 +123,7 @@ struct HdModel {
         int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
         int graph_qB = -1, graph_qoff = -1;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    } lane[2];
+    } lane[HD_MAX_LANES];
     int cl = 0;                                      // lane the helper functions currently address
     int nlanes = 1;
     // sampling session
@@ -914,10 +920,12 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_sample_begin: HD_DROPOUT_INJECT needs masks");
     // two concurrent half-batches unless the batch is small, masks are injected (their layout is per full batch)
     // or the caller asked for one lane
-    m->nlanes = (B >= 64 && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? 2 : 1;
-    const int B0 = m->nlanes == 2 ? (B + 1) / 2 : B;
-    m->lane[0].B = B0; m->lane[0].row_off = 0;
-    m->lane[1].B = B - B0; m->lane[1].row_off = B0;
+    m->nlanes = (B >= 64 && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? lanes_default() : 1;
+    for (int l = 0, off = 0; l < m->nlanes; ++l) {            // balanced contiguous row blocks
+        const int Bl = B / m->nlanes + (l < B % m->nlanes ? 1 : 0);
+        m->lane[l].B = Bl; m->lane[l].row_off = off;
+        off += Bl;
+    }
     std::vector<int32_t> chain_l;
     for (int l = 0; l < m->nlanes; ++l) {
         m->cl = l;
