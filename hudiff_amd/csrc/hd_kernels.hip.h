@@ -705,6 +705,17 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 
     const int qi = lane & 15, g = lane >> 4;
     const int nqt = (L + 15) / 16;
+    // raw Q rows of the NEXT tile are requested one tile ahead so that their L2 / HBM latency hides under the
+    // current tile's MFMAs
+    f32x4 qraw[4];
+    auto load_q = [&](int qt) {
+        const int qq = qt * 16 + qi;
+        const int qc = qq < L ? qq : L - 1;
+        const long qrow = sg.row(b, qc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qraw[s] = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + 16 * s + 4 * g);
+    };
+    if (wave < nqt) load_q(wave);
     for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
@@ -714,12 +725,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int c4 = 16 * s + 4 * g;
-            f32x4 v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
+            const f32x4 v = qraw[s];
             const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
             const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
             qf[s][0] = (v[0] * cs.x - v[1] * sn.x) * 0.125f; qf[s][1] = (v[0] * sn.x + v[1] * cs.x) * 0.125f;
             qf[s][2] = (v[2] * cs.y - v[3] * sn.y) * 0.125f; qf[s][3] = (v[2] * sn.y + v[3] * cs.y) * 0.125f;
         }
+        if (qt + ATT_THREADS / 64 < nqt) load_q(qt + ATT_THREADS / 64);
         // S^T tiles, two key tiles per pass so that two independent accumulator chains are in flight
         f32x4 st[NKT];
 #pragma unroll
