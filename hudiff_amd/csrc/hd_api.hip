@@ -602,15 +602,19 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
         }
     } else {
         switch (pro) {
+            case 0: HD_LAUNCH(true, 0); break;       // input already normalised + activated (ln_apply_k)
             case 2: HD_LAUNCH(true, 2); break;
-            default: HD_LAUNCH(true, 3); break;      // the ByteNet convolution always has LN + activation
+            default: HD_LAUNCH(true, 3); break;
         }
     }
 }
 #undef HD_LAUNCH
 
 // p.part != nullptr: the epilogue leaves LayerNorm partials of the output rows and they are merged into `stats_out`.
-static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float2* stats_out = nullptr) {
+struct LnApply { const float* gamma = nullptr; const float* beta = nullptr; int k_stride = 0; int act = 0; };
+
+static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float2* stats_out = nullptr,
+                        const LnApply* apply = nullptr) {
     const long rows = (long)p.sg.B * p.sg.L;
     const bool big = rows >= 8192;
     p.part_rows = rows;
@@ -620,7 +624,11 @@ static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
     }
-    if (p.part && stats_out)
+    if (p.part && apply) {      // normalise + activate the output in place (consumer: the tap GEMM, which then needs no prologue)
+        const int seg1 = p.sg.nseg > 1 ? p.sg.base[1] : (int)rows;
+        hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows,
+                           p.C, apply->gamma, apply->beta, apply->k_stride, seg1, apply->act);
+    } else if (p.part && stats_out)
         hipLaunchKernelGGL(ln_finalize_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows, stats_out);
 }
 
@@ -653,12 +661,14 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
     p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = m->lane[m->cl].ws.PART;
-    launch_gemm(p, false, true, st, m->lane[m->cl].ws.ST);
+    // h1 <- act(LN(h1)) in place, once, instead of in the tap GEMM's prologue (7 taps x N tiles times per element)
+    const LnApply ap{w.ln2_g, w.ln2_b, dh, act};
+    launch_gemm(p, false, true, st, nullptr, &ap);
 
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.pro_act = act; p.part = m->lane[m->cl].ws.PART;
+    p.part = m->lane[m->cl].ws.PART;
     launch_gemm(p, true, true, st, m->lane[m->cl].ws.ST);
 
     p = base_gemm(m, sg);

@@ -498,6 +498,41 @@ __global__ void __launch_bounds__(256) ln_finalize_k(const float2* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm + activation applied IN PLACE to a GEMM output whose epilogue left (mean, M2) slice partials:
+// used in front of the dilated convolution, which would otherwise redo the normalisation and the (erf) GELU
+// for each of its 7 taps and each of its N tiles.  One wave per row; gamma / beta are per chain segment.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ part, int pw, int C, int rows,
+                                                   float* __restrict__ X, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, int k_stride, int seg1_row0,
+                                                   int act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int P = (C + pw - 1) / pw;
+    float mean = 0.f;
+    for (int i = 0; i < P; ++i) mean += part[(long)i * rows + row].x * (float)min(pw, C - i * pw);
+    mean /= (float)C;
+    float m2 = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float2 pr = part[(long)i * rows + row];
+        const float d = pr.x - mean;
+        m2 += pr.y + (float)min(pw, C - i * pw) * d * d;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / (float)C + 1e-5f);
+    const int seg = row >= seg1_row0 ? 1 : 0;
+    const float* g = gamma + seg * k_stride;
+    const float* b = beta + seg * k_stride;
+    float* x = X + (long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *reinterpret_cast<f32x4*>(x + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_f((v[k] - mean) * rstd * gv[k] + bv[k], act);
+        *reinterpret_cast<f32x4*>(x + c) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm statistics: one wave per row, two-pass (mean, then centred variance), eps = 1e-5
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) row_stats_k(const float* __restrict__ X, int ldx, int C, int rows,
