@@ -193,6 +193,14 @@ def main():
                          "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)},
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
         }
+        # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            if tr["config"] == {"kind": kind, "rows_per_gpu": B, "dropout": args.dropout, "lanes": 1}:
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes per denoiser step, profiles/r01/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
+        except Exception:
+            pass
         if args.max_t > 0:
             out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
         if not args.no_cpu_baseline and n_gpus == 1:
