@@ -196,7 +196,8 @@ def main():
         # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            if tr["config"] == {"kind": kind, "rows_per_gpu": B, "dropout": args.dropout, "lanes": 1}:
+            c = tr["config"]      # measured with one lane; the bytes do not depend on how the batch is split into lanes
+            if (c["kind"], c["rows_per_gpu"], c["dropout"]) == (kind, B, args.dropout):
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = "bytes per denoiser step, profiles/r01/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
