@@ -136,6 +136,10 @@ struct HdModel {
     int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
 };
 
+// the lane (stream + workspace + graph) the helper functions currently address
+static inline HdModel::Lane& cur(HdModel* m) { return m->lane[m->cl]; }
+static inline const HdModel::Lane& cur(const HdModel* m) { return m->lane[m->cl]; }
+
 static int dilation_of(const HdConfig& c, int n) {
     int log2r = 0;
     while ((1 << (log2r + 1)) <= c.r) ++log2r;
@@ -502,16 +506,16 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     }
     m->cl = 0;
     HIP_TRY(hipMalloc(&m->emb_stats, sizeof(float2) * c.n_tokens));
-    hipLaunchKernelGGL(row_stats_k, dim3((c.n_tokens + 3) / 4), dim3(256), 0, m->lane[m->cl].stream, m->emb, d, d, c.n_tokens, m->emb_stats);
+    hipLaunchKernelGGL(row_stats_k, dim3((c.n_tokens + 3) / 4), dim3(256), 0, cur(m).stream, m->emb, d, d, c.n_tokens, m->emb_stats);
     if (ab) {
         HIP_TRY(hipMalloc(&m->side_vec, sizeof(float) * c.n_side * d));
-        hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, m->lane[m->cl].stream, m->sidew, se, d, m->side_vec);
+        hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, cur(m).stream, m->sidew, se, d, m->side_vec);
         HIP_TRY(hipGetLastError());
     }
     const size_t smem = (size_t)L * (ATT_KS + ATT_VS) * sizeof(float);
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
+    HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
     m->finalized = true;
     return HD_OK;
@@ -528,12 +532,12 @@ static HdStatus dalloc(Workspace& ws, T** p, size_t n) {
 }
 
 static HdStatus ensure_ws(HdModel* m, int B) {
-    Workspace& ws = m->lane[m->cl].ws;
+    Workspace& ws = cur(m).ws;
     if (B <= ws.capB) return HD_OK;
-    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
-    if (m->lane[m->cl].graph_exec) { hipGraphExecDestroy(m->lane[m->cl].graph_exec); m->lane[m->cl].graph_exec = nullptr; }
-    if (m->lane[m->cl].graph) { hipGraphDestroy(m->lane[m->cl].graph); m->lane[m->cl].graph = nullptr; }
-    m->lane[m->cl].graph_B = -1;
+    HIP_TRY(hipStreamSynchronize(cur(m).stream));
+    if (cur(m).graph_exec) { hipGraphExecDestroy(cur(m).graph_exec); cur(m).graph_exec = nullptr; }
+    if (cur(m).graph) { hipGraphDestroy(cur(m).graph); cur(m).graph = nullptr; }
+    cur(m).graph_B = -1;
     free_ws(ws);
     const size_t M = (size_t)B * m->L;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, A = m->A, Fd = m->Fd;
@@ -566,7 +570,7 @@ struct Drop { int mode = DROP_NONE; float p = 0.f; uint32_t site = 0; const uint
 
 static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     GemmP p{};
-    p.sg = sg; p.taps = 1; p.dil = 1; p.rs = m->lane[m->cl].rs;
+    p.sg = sg; p.taps = 1; p.dil = 1; p.rs = cur(m).rs;
     return p;
 }
 
@@ -633,7 +637,7 @@ static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float
 }
 
 static void launch_stats(const HdModel* m, const float* X, int ldx, int C, int rows, hipStream_t st) {
-    hipLaunchKernelGGL(row_stats_k, dim3((rows + 3) / 4), dim3(256), 0, st, X, ldx, C, rows, m->lane[m->cl].ws.ST);
+    hipLaunchKernelGGL(row_stats_k, dim3((rows + 3) / 4), dim3(256), 0, st, X, ldx, C, rows, cur(m).ws.ST);
 }
 
 static void set_drop(GemmP& p, const Drop& dr) {
@@ -653,14 +657,14 @@ static void set_drop(GemmP& p, const Drop& dr) {
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
                           const Drop& dr, const float* extra, int lde, bool x_stats_ready, bool want_out_stats) {
-    hipStream_t st = m->lane[m->cl].stream;
+    hipStream_t st = cur(m).stream;
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
     if (!x_stats_ready) launch_stats(m, x, ldx, din, rows, st);
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
-    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = m->lane[m->cl].ws.PART;
+    p.stats = cur(m).ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = cur(m).ws.PART;
     // h1 <- act(LN(h1)) in place, once, instead of in the tap GEMM's prologue (7 taps x N tiles times per element)
     const LnApply ap{w.ln2_g, w.ln2_b, dh, act};
     launch_gemm(p, false, true, st, nullptr, &ap);
@@ -668,44 +672,44 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    p.part = m->lane[m->cl].ws.PART;
-    launch_gemm(p, true, true, st, m->lane[m->cl].ws.ST);
+    p.part = cur(m).ws.PART;
+    launch_gemm(p, true, true, st, cur(m).ws.ST);
 
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
-    p.stats = m->lane[m->cl].ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    p.stats = cur(m).ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     set_drop(p, dr);
-    if (want_out_stats) p.part = m->lane[m->cl].ws.PART;
-    launch_gemm(p, false, true, st, m->lane[m->cl].ws.ST);
+    if (want_out_stats) p.part = cur(m).ws.PART;
+    launch_gemm(p, false, true, st, cur(m).ws.ST);
 }
 
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
                             const float* g, const float* b, const float* resid, float* out, bool want_out_stats) {
-    hipStream_t st = m->lane[m->cl].stream;
+    hipStream_t st = cur(m).stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
-    p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = m->lane[m->cl].ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
-    if (ln) { p.stats = m->lane[m->cl].ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
+    p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
+    if (ln) { p.stats = cur(m).ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
     launch_gemm(p, false, false, st);
     const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
     if (m->L > 160)
-        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, m->lane[m->cl].ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->lane[m->cl].ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg);
     else
-        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, m->lane[m->cl].ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, m->lane[m->cl].ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg);
     p = base_gemm(m, sg);
-    p.A = m->lane[m->cl].ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
+    p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    if (want_out_stats) p.part = m->lane[m->cl].ws.PART;
-    launch_gemm(p, false, false, st, m->lane[m->cl].ws.ST);
+    if (want_out_stats) p.part = cur(m).ws.PART;
+    launch_gemm(p, false, false, st, cur(m).ws.ST);
 }
 
 // The token-independent branch (RegionEmbedder, PosEmbedder, SideEmbedder): once per batch.
 static HdStatus static_branch(HdModel* m, const Segs& sg) {
-    hipStream_t st = m->lane[m->cl].stream;
-    Workspace& ws = m->lane[m->cl].ws;
+    hipStream_t st = cur(m).stream;
+    Workspace& ws = cur(m).ws;
     const int d = m->d, D = m->D, rows = sg.rows();
     hipLaunchKernelGGL(region_embed_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.region, m->regw, m->cfg.r_embedding, d, ws.POS, sg);
     // pos = x + W2 gelu(W1 x + b1) + b2      (MLP model.py:28-33; nn.Dropout is inactive in eval mode)
@@ -725,8 +729,8 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
 // Last SelfAttBlock of a sampling step, from "at = x + A1(x)" (in ws.AT, statistics in ws.ST) on, evaluated only
 // for the row each sequence visits at this step (see gather_rows_k).  Result: ws.Xc [B, D] = block output rows.
 static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
-    hipStream_t st = m->lane[m->cl].stream;
-    Workspace& ws = m->lane[m->cl].ws;
+    hipStream_t st = cur(m).stream;
+    Workspace& ws = cur(m).ws;
     const int D = m->D, A = m->A, Fd = m->Fd, B = sg.B;
     Segs cs{};                      // compact [B, *] matrices: one "sequence" of B single-slot rows
     cs.nseg = 1; cs.B = B; cs.L = 1; cs.len[0] = 1;
@@ -736,8 +740,8 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.N = 2 * A; p.Kc = D; p.stats = ws.ST; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
     launch_gemm(p, false, false, st);
     // visited rows of `at` and of the block input x
-    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
-    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
+    hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
     hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
     // q = LN1(at_c) Wq + bq
     p = base_gemm(m, cs);
@@ -745,7 +749,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.stats = ws.STc; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
     launch_gemm(p, false, false, st);
     hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
-                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, m->lane[m->cl].rs, sg);
+                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
     // at_c = at_c + o Wo + bo
     p = base_gemm(m, cs);
     p.A = ws.Oc; p.lda = A; p.W = w.a2.wo; p.bias = w.a2.bo; p.C = ws.ATc; p.ldc = D; p.N = D; p.Kc = A; p.resid = ws.ATc; p.ldr = D;
@@ -764,8 +768,8 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
 // One denoiser forward up to the last attention block; result rows in ws.Y.
 static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks,
                              bool prune_last = false) {
-    hipStream_t st = m->lane[m->cl].stream;
-    Workspace& ws = m->lane[m->cl].ws;
+    hipStream_t st = cur(m).stream;
+    Workspace& ws = cur(m).ws;
     const HdConfig& c = m->cfg;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
     hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
@@ -824,19 +828,19 @@ static HdStatus validate_inputs(const HdModel* m, const int32_t* tokens, const i
 }
 
 static HdStatus upload_common(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain, int B) {
-    Workspace& ws = m->lane[m->cl].ws;
+    Workspace& ws = cur(m).ws;
     const size_t M = (size_t)B * m->L;
-    HIP_TRY(hipMemcpyAsync(ws.tokens, tokens, M * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
-    HIP_TRY(hipMemcpyAsync(ws.region, region, M * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
-    if (m->nseg > 1) HIP_TRY(hipMemcpyAsync(ws.chain, chain, (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice, m->lane[m->cl].stream));
+    HIP_TRY(hipMemcpyAsync(ws.tokens, tokens, M * sizeof(int32_t), hipMemcpyHostToDevice, cur(m).stream));
+    HIP_TRY(hipMemcpyAsync(ws.region, region, M * sizeof(int32_t), hipMemcpyHostToDevice, cur(m).stream));
+    if (m->nseg > 1) HIP_TRY(hipMemcpyAsync(ws.chain, chain, (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice, cur(m).stream));
     return HD_OK;
 }
 
 static HdStatus set_run_state(HdModel* m, uint64_t seed, uint64_t row0, uint32_t step) {
     RunState h{};
     h.step = step; h.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu); h.seed_hi = (uint32_t)(seed >> 32); h.row0 = (uint32_t)row0;
-    HIP_TRY(hipMemcpyAsync(m->lane[m->cl].rs, &h, sizeof(h), hipMemcpyHostToDevice, m->lane[m->cl].stream));
-    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));   // h is a stack object
+    HIP_TRY(hipMemcpyAsync(cur(m).rs, &h, sizeof(h), hipMemcpyHostToDevice, cur(m).stream));
+    HIP_TRY(hipStreamSynchronize(cur(m).stream));   // h is a stack object
     return HD_OK;
 }
 
@@ -850,7 +854,7 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 template <typename T>
 static HdStatus ensure_buf(HdModel* m, T** p, size_t* cap, size_t n) {
     if (n <= *cap) return HD_OK;
-    HD_TRY(dalloc(m->lane[m->cl].ws, p, n));
+    HD_TRY(dalloc(cur(m).ws, p, n));
     *cap = n;
     return HD_OK;
 }
@@ -869,7 +873,7 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
     const int dm = drop_mode_of(m, flags);
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_forward: HD_DROPOUT_INJECT needs enc_masks and conv_masks");
     HD_TRY(ensure_ws(m, B));
-    Workspace& ws = m->lane[m->cl].ws;
+    Workspace& ws = cur(m).ws;
     const Segs sg = make_segs(m, B);
     HD_TRY(upload_common(m, tokens, region, chain, B));
     HD_TRY(set_run_state(m, seed, row0, step));
@@ -878,23 +882,23 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
         const size_t ne = (size_t)m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)m->cfg.dual_layers * B * m->L * m->D;
         HD_TRY(ensure_buf(m, &ws.enc_masks, &ws.enc_cap, ne));
         HD_TRY(ensure_buf(m, &ws.conv_masks, &ws.conv_cap, nc));
-        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, m->lane[m->cl].stream));
-        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, m->lane[m->cl].stream));
+        HIP_TRY(hipMemcpyAsync(ws.enc_masks, enc_masks, ne, hipMemcpyHostToDevice, cur(m).stream));
+        HIP_TRY(hipMemcpyAsync(ws.conv_masks, conv_masks, nc, hipMemcpyHostToDevice, cur(m).stream));
         dem = ws.enc_masks; dcm = ws.conv_masks;
     }
     HD_TRY(static_branch(m, sg));
     HD_TRY(forward_body(m, sg, dm, dem, dcm));
     const int rows = sg.rows();
-    hipLaunchKernelGGL(decode_all_k, dim3((rows + 3) / 4), dim3(256), 0, m->lane[m->cl].stream, ws.Y, m->D, m->head, m->cfg.n_tokens, ws.LOGITS, sg);
+    hipLaunchKernelGGL(decode_all_k, dim3((rows + 3) / 4), dim3(256), 0, cur(m).stream, ws.Y, m->D, m->head, m->cfg.n_tokens, ws.LOGITS, sg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, m->lane[m->cl].stream));
-    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
+    HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, cur(m).stream));
+    HIP_TRY(hipStreamSynchronize(cur(m).stream));
     return HD_OK;
 }
 
 // ---- sampling session ---------------------------------------------------------------------------
 static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, const uint8_t* cm) {
-    HdModel::Lane& ln = m->lane[m->cl];
+    HdModel::Lane& ln = cur(m);
     const bool prune = !(m->sflags & HD_NO_PRUNE);
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = ln.ws;
@@ -1107,7 +1111,7 @@ extern "C" HdStatus hd_debug_stop_after(HdModel* m, int32_t stage) {
 extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats) {
     if (!m || !name || !out) return fail(HD_ERR_INVALID, "hd_debug_read: null argument");
     HIP_TRY(hipSetDevice(m->device));
-    const Workspace& ws = m->lane[m->cl].ws;
+    const Workspace& ws = cur(m).ws;
     const std::string k(name);
     const float* src = nullptr;
     int width = 0;
@@ -1121,7 +1125,7 @@ extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float
     if (B > ws.capB || n_floats != (int64_t)B * m->L * width) return fail(HD_ERR_INVALID, "hd_debug_read: size mismatch");
     // rows are segment-major on the device; return them as [B, L, width]
     std::vector<float> tmp((size_t)n_floats);
-    HIP_TRY(hipStreamSynchronize(m->lane[m->cl].stream));
+    HIP_TRY(hipStreamSynchronize(cur(m).stream));
     HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
     const Segs sg = make_segs(m, B);
     for (int b = 0; b < B; ++b)
