@@ -10,6 +10,8 @@ from __future__ import annotations
 import os
 from typing import Optional, Tuple
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this driver stack
+
 import numpy as np
 
 
