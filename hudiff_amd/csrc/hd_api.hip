@@ -72,7 +72,9 @@ struct Workspace {
     float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float2* ST = nullptr;
-    float2* PART = nullptr;                                  // [M, PART_STRIDE] LayerNorm partials from GEMM epilogues
+    float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
+    int part_next = 0;                                       // buffer the next producing GEMM writes
+    const float2* part_last = nullptr; int part_last_pw = 0; // what the last producing GEMM wrote (for its consumer)
     float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
     float *ATc = nullptr, *Xc = nullptr, *Qc = nullptr, *Oc = nullptr, *F1c = nullptr;   // pruned last block: [B, *]
     float2* STc = nullptr;
@@ -547,7 +549,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.QKV, M * 3 * A)); HD_TRY(dalloc(ws, &ws.O, M * A)); HD_TRY(dalloc(ws, &ws.AT, M * D));
     HD_TRY(dalloc(ws, &ws.F1, M * Fd));
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
-    HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART, M * PART_STRIDE));
+    HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART[0], M * PART_STRIDE)); HD_TRY(dalloc(ws, &ws.PART[1], M * PART_STRIDE));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
@@ -595,7 +597,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     q.tiles_m = q.tiles0 + (rows1 + BM - 1) / BM;
     q.tiles_n = (q.N + BN - 1) / BN;
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
-    const int pro = q.stats ? 1 + q.pro_act : 0;      // 0 none, 1 LN, 2 LN+ReLU, 3 LN+GELU
+    const int pro = (q.stats || q.spart) ? 1 + q.pro_act : 0;      // 0 none, 1 LN, 2 LN+ReLU, 3 LN+GELU
 #define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, 1, BKT>), grid, blk, 0, st, q)
     if (!conv) {
         switch (pro) {
@@ -616,24 +618,37 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
 
 // p.part != nullptr: the epilogue leaves LayerNorm partials of the output rows and they are merged into `stats_out`.
 struct LnApply { const float* gamma = nullptr; const float* beta = nullptr; int k_stride = 0; int act = 0; };
+enum StatsOut { STATS_NONE = 0, STATS_PARTIALS = 1 };
 
-static void launch_gemm(GemmP& p, bool conv, bool per_seg, hipStream_t st, float2* stats_out = nullptr,
-                        const LnApply* apply = nullptr) {
+// Output LayerNorm statistics: STATS_PARTIALS leaves the epilogue's slice partials for a consumer GEMM that merges
+// them in its prologue (use_partials()); `apply` normalises + activates the output in place instead (ln_apply_k).
+static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats_out = STATS_NONE, const LnApply* apply = nullptr) {
+    Workspace& ws = cur(m).ws;
+    hipStream_t st = cur(m).stream;
     const long rows = (long)p.sg.B * p.sg.L;
     const bool big = rows >= 8192;
+    const int pw = big ? 64 : 32;
     p.part_rows = rows;
+    if (stats_out != STATS_NONE || apply) p.part = ws.PART[ws.part_next];
     if (big) {
         if (gemm_bk() == 32) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
         else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
     }
-    if (p.part && apply) {      // normalise + activate the output in place (consumer: the tap GEMM, which then needs no prologue)
+    if (!p.part) return;
+    ws.part_last = p.part; ws.part_last_pw = pw; ws.part_next ^= 1;
+    if (apply) {      // normalise + activate the output in place (consumer: the tap GEMM, which then needs no prologue)
         const int seg1 = p.sg.nseg > 1 ? p.sg.base[1] : (int)rows;
-        hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows,
+        hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, pw, p.N, (int)rows,
                            p.C, apply->gamma, apply->beta, apply->k_stride, seg1, apply->act);
-    } else if (p.part && stats_out)
-        hipLaunchKernelGGL(ln_finalize_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.part, big ? 64 : 32, p.N, (int)rows, stats_out);
+    }
+}
+
+// prologue statistics of `p` = the slice partials the previous producing GEMM left (merged in the kernel)
+static void use_partials(HdModel* m, GemmP& p) {
+    const Workspace& ws = cur(m).ws;
+    p.stats = nullptr; p.spart = ws.part_last; p.spw = ws.part_last_pw; p.spart_rows = (long)p.sg.B * p.sg.L;
 }
 
 static void launch_stats(const HdModel* m, const float* X, int ldx, int C, int rows, hipStream_t st) {
@@ -650,49 +665,55 @@ static void set_drop(GemmP& p, const Drop& dr) {
     p.drop_mask = dr.mask;
 }
 
+// Where the LayerNorm statistics of a GEMM's input rows come from
+enum XStats { X_FINAL = 0,      // ws.ST already holds (mean, rstd)
+              X_PARTIALS = 1,   // the previous GEMM left slice partials (merged in the prologue)
+              X_NONE = 2 };     // nothing yet: run row_stats_k
+
 // One ByteNet block:  out = dropout(x + PFF2(act(LN(conv(act(LN(PFF1(act(LN(x))))))))))   [+ extra]
-// LayerNorm statistics travel with the data: every GEMM epilogue leaves the statistics of the rows it wrote
-// (ws.PART -> ws.ST) for the next GEMM's prologue.  x_stats_ready: ws.ST already describes x;
-// want_out_stats: leave the statistics of `out` in ws.ST for the next block.
+// LayerNorm statistics travel with the data: every GEMM epilogue leaves (mean, M2) slice partials of the rows it
+// wrote and the next GEMM merges them in its prologue; in front of the tap GEMM, LayerNorm + activation are applied
+// once in place (ln_apply_k).  want_out_stats: leave partials of `out` for the next block's first GEMM.
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
-                          const Drop& dr, const float* extra, int lde, bool x_stats_ready, bool want_out_stats) {
-    hipStream_t st = cur(m).stream;
+                          const Drop& dr, const float* extra, int lde, XStats x_stats, bool want_out_stats) {
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
-    if (!x_stats_ready) launch_stats(m, x, ldx, din, rows, st);
+    if (x_stats == X_NONE) launch_stats(m, x, ldx, din, rows, cur(m).stream);
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
-    p.stats = cur(m).ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act; p.part = cur(m).ws.PART;
+    p.stats = cur(m).ws.ST; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.pro_act = act;
+    if (x_stats == X_PARTIALS) use_partials(m, p);
     // h1 <- act(LN(h1)) in place, once, instead of in the tap GEMM's prologue (7 taps x N tiles times per element)
     const LnApply ap{w.ln2_g, w.ln2_b, dh, act};
-    launch_gemm(p, false, true, st, nullptr, &ap);
+    launch_gemm(m, p, false, true, STATS_NONE, &ap);
 
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    p.part = cur(m).ws.PART;
-    launch_gemm(p, true, true, st, cur(m).ws.ST);
+    launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
-    p.stats = cur(m).ws.ST; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    use_partials(m, p);
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     set_drop(p, dr);
-    if (want_out_stats) p.part = cur(m).ws.PART;
-    launch_gemm(p, false, true, st, cur(m).ws.ST);
+    launch_gemm(m, p, false, true, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
+// out = resid + Attn(x) (AttLayer, cross_attention.py:149-173).  ln: x is LayerNorm'ed with (g, b) in the fused Q|K|V
+// projection's prologue, its statistics being the partials the previous GEMM left.
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
                             const float* g, const float* b, const float* resid, float* out, bool want_out_stats) {
     hipStream_t st = cur(m).stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
-    if (ln) { p.stats = cur(m).ws.ST; p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; }
-    launch_gemm(p, false, false, st);
+    if (ln) { p.gamma = g; p.beta = b; p.pro_act = ACT_NONE; use_partials(m, p); }
+    launch_gemm(m, p, false, false);
     const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
     if (m->L > 160)
@@ -702,8 +723,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p = base_gemm(m, sg);
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    if (want_out_stats) p.part = cur(m).ws.PART;
-    launch_gemm(p, false, false, st, cur(m).ws.ST);
+    launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
 // The token-independent branch (RegionEmbedder, PosEmbedder, SideEmbedder): once per batch.
@@ -715,11 +735,11 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
     // pos = x + W2 gelu(W1 x + b1) + b2      (MLP model.py:28-33; nn.Dropout is inactive in eval mode)
     GemmP p = base_gemm(m, sg);
     p.A = ws.POS; p.lda = d; p.W = m->pos_w1; p.bias = m->pos_b1; p.C = ws.PH; p.ldc = 2 * d; p.N = 2 * d; p.Kc = d; p.epi_act = ACT_GELU;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
     p = base_gemm(m, sg);
     p.A = ws.PH; p.lda = 2 * d; p.W = m->pos_w2; p.bias = m->pos_b2; p.C = ws.POS; p.ldc = d; p.N = d; p.Kc = 2 * d;
     p.resid = ws.POS; p.ldr = d;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
     hipLaunchKernelGGL(static_feature_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.POS,
                        m->nseg > 1 ? m->side_vec : nullptr, ws.chain, d, D, ws.EXTRA, ws.FEAT, sg);
     HIP_TRY(hipGetLastError());
@@ -737,8 +757,9 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     // K | V projections of LN1(at) for every row (columns [A, 3A) of the fused weight)
     GemmP p = base_gemm(m, sg);
     p.A = ws.AT; p.lda = D; p.W = w.a2.wqkv + A; p.ldw = 3 * A; p.bias = w.a2.bqkv + A; p.C = ws.QKV + A; p.ldc = 3 * A;
-    p.N = 2 * A; p.Kc = D; p.stats = ws.ST; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
-    launch_gemm(p, false, false, st);
+    p.N = 2 * A; p.Kc = D; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
+    use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
+    launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -747,22 +768,22 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p = base_gemm(m, cs);
     p.A = ws.ATc; p.lda = D; p.W = w.a2.wqkv; p.ldw = 3 * A; p.bias = w.a2.bqkv; p.C = ws.Qc; p.ldc = A; p.N = A; p.Kc = D;
     p.stats = ws.STc; p.gamma = w.n1_g; p.beta = w.n1_b; p.pro_act = ACT_NONE;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
     hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
                        m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
     // at_c = at_c + o Wo + bo
     p = base_gemm(m, cs);
     p.A = ws.Oc; p.lda = A; p.W = w.a2.wo; p.bias = w.a2.bo; p.C = ws.ATc; p.ldc = D; p.N = D; p.Kc = A; p.resid = ws.ATc; p.ldr = D;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
     // x_c = FF(LN2(at_c)) + x_c
     hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
     p = base_gemm(m, cs);
     p.A = ws.ATc; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1c; p.ldc = Fd; p.N = Fd; p.Kc = D;
     p.stats = ws.STc; p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
     p = base_gemm(m, cs);
     p.A = ws.F1c; p.lda = Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Xc; p.ldc = D; p.N = D; p.Kc = Fd; p.resid = ws.Xc; p.ldr = D;
-    launch_gemm(p, false, false, st);
+    launch_gemm(m, p, false, false);
 }
 
 // One denoiser forward up to the last attention block; result rows in ws.Y.
@@ -779,7 +800,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
         bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
-                      last ? ws.EXTRA : nullptr, d, /*x_stats_ready=*/true, /*want_out_stats=*/!last);
+                      last ? ws.EXTRA : nullptr, d, n == 0 ? X_FINAL : X_PARTIALS, /*want_out_stats=*/!last);
     }
     if (m->debug_stop_after == 1) return HD_OK;
     for (int n = 0; n < c.dual_layers; ++n) {
@@ -787,7 +808,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
-                      /*x_stats_ready=*/n > 0, /*want_out_stats=*/n + 1 < c.dual_layers);
+                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
         if (m->debug_stop_after == 2 + n) return HD_OK;
@@ -800,12 +821,13 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
-        p.stats = ws.ST; p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;
-        launch_gemm(p, false, false, st);
+        p.gamma = w.n2_g; p.beta = w.n2_b; p.pro_act = ACT_NONE; p.epi_act = ACT_RELU;
+        use_partials(m, p);         // statistics of `at`: partials left by the second attention's out-projection
+        launch_gemm(m, p, false, false);
         p = base_gemm(m, sg);
         p.A = ws.F1; p.lda = m->Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Y; p.ldc = D; p.N = D; p.Kc = m->Fd;
         p.resid = ws.Y; p.ldr = D;
-        launch_gemm(p, false, false, st);
+        launch_gemm(m, p, false, false);
     }
     HIP_TRY(hipGetLastError());
     return HD_OK;

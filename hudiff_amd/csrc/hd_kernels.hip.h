@@ -121,6 +121,8 @@ struct GemmP {
     long w_stride; int n_stride; int k_stride;   // per-segment strides of W / bias / (gamma, beta)
     // prologue: LayerNorm over the Kc features of each A row, then activation
     const float2* stats;              // [rows] (mean, rstd) or null
+    const float2* spart; int spw;     // alternative to `stats`: the producer's slice partials [PART_STRIDE][rows] and its
+    long spart_rows;                  // slice width; merged on the fly in the prologue (non-CONV only)
     const float* gamma; const float* beta;
     int pro_act;
     // epilogue
@@ -130,7 +132,7 @@ struct GemmP {
     int drop_mode; uint32_t drop_thresh; float drop_scale; uint32_t drop_site;
     const uint8_t* drop_mask;         // [B, L, N] keep-mask (DROP_INJECT)
     const RunState* rs;
-    float2* part; long part_rows;     // optional [PART_STRIDE][part_rows] LayerNorm partials of the OUTPUT rows (ln_finalize_k)
+    float2* part; long part_rows;     // optional [PART_STRIDE][part_rows] LayerNorm (mean, M2) slice partials of the OUTPUT rows
     // geometry
     Segs sg;
     int tiles0;                       // number of M tiles of segment 0
@@ -223,7 +225,23 @@ __global__ void __launch_bounds__(256, (NBUF == 1 && BK == 16) ? 4 : (NBUF == 1 
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;  // clamped: always a readable row
         a_st[i] = make_float2(0.f, 0.f);
-        if (PRO && !CONV) a_st[i] = p.stats[a_row[i]];
+        if (PRO && !CONV) {
+            if (p.spart) {          // merge the producing GEMM's (mean, M2) slice partials (Chan et al.)
+                const int P = (Kc + p.spw - 1) / p.spw;
+                float mean = 0.f;
+                for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + a_row[i]].x * (float)min(p.spw, Kc - s * p.spw);
+                mean /= (float)Kc;
+                float m2 = 0.f;
+                for (int s = 0; s < P; ++s) {
+                    const float2 pr = p.spart[(long)s * p.spart_rows + a_row[i]];
+                    const float d = pr.x - mean;
+                    m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
+                }
+                a_st[i] = make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+            } else {
+                a_st[i] = p.stats[a_row[i]];
+            }
+        }
     }
     constexpr int B_KSTEP = 256 / (BN / 4);
     const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);
@@ -447,7 +465,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 && BK == 16) ? 4 : (NBUF == 1 
             if (p.part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
                 // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
-                // deviations) of its slice with xor-shuffles and ln_finalize_k merges the slices exactly
+                // deviations) of its slice with DPP row reductions and the consumer merges the slices exactly
                 // (Chan et al.), which spares a separate read pass over the activation.
                 const bool valid = lrow < seg_rows && col_ok;
                 const int nv = min(WTN, N - (n0 + wn * WTN));                 // valid columns of this slice (uniform)
@@ -476,25 +494,6 @@ __global__ void __launch_bounds__(256, (NBUF == 1 && BK == 16) ? 4 : (NBUF == 1 
                 p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Merge the per-slice (mean, M2) partials a GEMM epilogue left for each output row into (mean, rstd).
-// pw = slice width (the producing kernel's wave-tile width), C = row width.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ln_finalize_k(const float2* __restrict__ part, int pw, int C, int rows,
-                                                      float2* __restrict__ stats) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
-    const int P = (C + pw - 1) / pw;
-    float2 pr[PART_STRIDE];
-    for (int i = 0; i < P; ++i) pr[i] = part[(long)i * rows + row];
-    float mean = 0.f;
-    for (int i = 0; i < P; ++i) mean += pr[i].x * (float)min(pw, C - i * pw);
-    mean /= (float)C;
-    float m2 = 0.f;
-    for (int i = 0; i < P; ++i) { const float d = pr[i].x - mean; m2 += pr[i].y + (float)min(pw, C - i * pw) * d * d; }
-    stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)C + 1e-5f));
 }
 
 // ------------------------------------------------------------------------------------------------
