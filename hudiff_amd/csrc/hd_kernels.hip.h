@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(256) static_feature_k(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_HD = 64;
 constexpr int ATT_KS = 68;   // K row stride in LDS (floats): 16-B aligned, spreads ds_read_b128 banks
-constexpr int ATT_VS = 64;
+constexpr int ATT_VS = 68;   // V row stride: rows 4 apart land 16 banks apart, so the 4 key rows a ds_read_b32 touches do not collide
 constexpr int ATT_MAX_KT = 19;   // ceil(291 / 16)
 
 constexpr int ATT_THREADS = 512;   // 8 waves, two per SIMD: one wave's softmax / LDS latency hides under the other's MFMAs
@@ -812,22 +812,34 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
-        // O^T[d, q] = sum_key V[key, d] P[key, q]
+        // O^T[d, q] = sum_key V[key, d] P[key, q]; the V fragments of key tile kt+1 are read while the MFMAs of
+        // tile kt run (register double buffer, order pinned with sched_group_barrier)
         f32x4 oacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; oacc[dt] = z; }
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        float vf[2][16];
+        auto load_v = [&](int kt, float (&dst)[16]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 16 + 4 * g + r;
                 key = key < L ? key : L - 1;            // P is exactly 0 there
                 const float* vp = Vs + key * ATT_VS + qi;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * dt], st[kt][r], oacc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) dst[4 * r + dt] = vp[16 * dt];
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_v(0, vf[0]);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int c = kt & 1;
+            if (kt + 1 < NKT) load_v(kt + 1, vf[c ^ 1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c][4 * r + dt], st[kt][r], oacc[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
         if (q < L) {
 #pragma unroll
