@@ -630,7 +630,12 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     const int pw = big ? 64 : 32;
     p.part_rows = rows;
     if (stats_out != STATS_NONE || apply) p.part = ws.PART[ws.part_next];
-    if (big) {
+    static const int small_tiles = [] { const char* e = getenv("HUDIFF_GEMM_SMALL"); return e ? atoi(e) : 1536; }();
+    const long tiles128 = ((rows + 127) / 128) * ((p.N + 127) / 128);
+    if (big && tiles128 < small_tiles) {
+        // few 128-row tiles (narrow outputs of the token encoder): 64-row tiles balance the 256 CUs better
+        launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
+    } else if (big) {
         if (gemm_bk() == 32) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
         else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else {
