@@ -150,6 +150,124 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
     return v;
 }
 
+// Shared GEMM epilogue: each wave transposes its accumulators through its own slice of LDS so that every lane owns
+// 4 consecutive columns of one row, then applies bias / activation / residual / dropout / addend on float4s, writes
+// with 16-B stores and (optionally) leaves the LayerNorm slice partials of the rows it wrote.
+// smem must hold 4 * 32 * (BN/WN + 4) + 4 * (BM/WM) * 2 floats and be free (all waves past their last LDS read).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                              int seg, int seg_rows, int rbase, int Lc, int m0, int n0, int by) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ES = WTN + 4;
+    constexpr int EPI_FLOATS = 4 * 32 * ES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int khalf = lane >> 5;
+    const int N = p.N;
+    const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
+    uint32_t k0 = 0, k1 = 0, row0 = 0;
+    if (p.drop_mode == DROP_GEN) {
+        uint32_t o[4];
+        philox4x32_10(0u, 0u, p.rs->step, p.drop_site, p.rs->seed_lo, p.rs->seed_hi, o);
+        k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
+    }
+    float* stage = smem + wave * (32 * ES);           // private to this wave: no block barrier needed
+    float2* wpart = reinterpret_cast<float2*>(smem + EPI_FLOATS) + wave * WTM;
+    constexpr int LPR = WTN / 4;                      // lanes per staged row (float4 each)
+    constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+    const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
+    const int col = n0 + wn * WTN + e_c4;
+    const bool col_ok = col < N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // residual values of this pass are requested up front (each lane reads exactly the elements it will
+        // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
+        // while the accumulators are transposed through LDS instead of serialising load -> store per row
+        f32x4 rres[32 / RPI];
+        if (p.resid) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int lrow = m0 + wm * WTM + 32 * i + it * RPI + e_r;
+                const long grow = (lrow < seg_rows) ? (long)rbase + lrow : (long)rbase;
+                rres[it] = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + (col_ok ? col : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * ES + 32 * j + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + e_r;
+            const int lrow = m0 + wm * WTM + 32 * i + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
+            if (lrow < seg_rows && col_ok) {
+                const long grow = (long)rbase + lrow;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
+                if (p.resid) v += rres[it];
+                if (p.drop_mode != DROP_NONE) {
+                    const int b = lrow / Lc;
+                    const int slot = p.sg.off[seg] + (lrow - b * Lc);
+                    if (p.drop_mode == DROP_GEN) {
+                        const uint32_t rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t w = mix32(rk + (uint32_t)(slot * N + col + c) * 0x9E3779B9U);
+                            v[c] = (w >= p.drop_thresh) ? v[c] * p.drop_scale : 0.f;
+                        }
+                    } else {
+                        const uint8_t* mk = p.drop_mask + ((long)b * p.sg.L + slot) * N + col;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = mk[c] ? v[c] * p.drop_scale : 0.f;
+                    }
+                }
+                if (p.extra) {
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(p.extra + grow * p.lde + col);
+                    v += ev;
+                }
+                *reinterpret_cast<f32x4*>(p.C + grow * p.ldc + col) = v;
+            }
+            if (p.part) {
+                // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
+                // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
+                // deviations) of its slice with DPP row reductions and the consumer merges the slices exactly
+                // (Chan et al.), which spares a separate read pass over the activation.
+                const bool valid = lrow < seg_rows && col_ok;
+                const int nv = min(WTN, N - (n0 + wn * WTN));                 // valid columns of this slice (uniform)
+                float ps = valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+                ps = group_sum<LPR>(ps);
+                const float pm = ps / (float)max(nv, 1);
+                float pq = 0.f;
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float d = v[c] - pm; pq += d * d; }
+                }
+                pq = group_sum<LPR>(pq);
+                if ((lane % LPR) == 0) wpart[32 * i + rr] = make_float2(pm, pq);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
+    }
+    if (p.part) {
+        // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int nv = min(WTN, N - (n0 + wn * WTN));
+        for (int r = lane; r < WTM; r += 64) {
+            const int lrow = m0 + wm * WTM + r;
+            if (lrow < seg_rows && nv > 0)
+                p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
+        }
+    }
+}
+
 // ABLATE (probe builds only, scripts/gemm_probe.hip): 1 = no global loads inside the K loop,
 // 2 = additionally no LDS commit / barrier, 3 = MFMAs only.  0 in the product.
 //
@@ -392,108 +510,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 && BK == 16) ? 4 : (NBUF == 1 
     }
     if (NBUF == 2) __syncthreads();
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
-    uint32_t k0 = 0, k1 = 0, row0 = 0;
-    if (p.drop_mode == DROP_GEN) {
-        uint32_t o[4];
-        philox4x32_10(0u, 0u, p.rs->step, p.drop_site, p.rs->seed_lo, p.rs->seed_hi, o);
-        k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
-    }
-    float* stage = smem + wave * (32 * ES);           // private to this wave: no block barrier needed
-    float2* wpart = reinterpret_cast<float2*>(smem + EPI_FLOATS) + wave * WTM;
-    constexpr int LPR = WTN / 4;                      // lanes per staged row (float4 each)
-    constexpr int RPI = 64 / LPR;                     // rows per wave instruction
-    const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
-    const int col = n0 + wn * WTN + e_c4;
-    const bool col_ok = col < N;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        // residual values of this pass are requested up front (each lane reads exactly the elements it will
-        // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
-        // while the accumulators are transposed through LDS instead of serialising load -> store per row
-        f32x4 rres[32 / RPI];
-        if (p.resid) {
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; ++it) {
-                const int lrow = m0 + wm * WTM + 32 * i + it * RPI + e_r;
-                const long grow = (lrow < seg_rows) ? (long)rbase + lrow : (long)rbase;
-                rres[it] = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + (col_ok ? col : 0));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * ES + 32 * j + (lane & 31)] = acc[i][j][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): this wave's LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rr = it * RPI + e_r;
-            const int lrow = m0 + wm * WTM + 32 * i + rr;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
-            if (lrow < seg_rows && col_ok) {
-                const long grow = (long)rbase + lrow;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
-                if (p.resid) v += rres[it];
-                if (p.drop_mode != DROP_NONE) {
-                    const int b = lrow / Lc;
-                    const int slot = p.sg.off[seg] + (lrow - b * Lc);
-                    if (p.drop_mode == DROP_GEN) {
-                        const uint32_t rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t w = mix32(rk + (uint32_t)(slot * N + col + c) * 0x9E3779B9U);
-                            v[c] = (w >= p.drop_thresh) ? v[c] * p.drop_scale : 0.f;
-                        }
-                    } else {
-                        const uint8_t* mk = p.drop_mask + ((long)b * p.sg.L + slot) * N + col;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = mk[c] ? v[c] * p.drop_scale : 0.f;
-                    }
-                }
-                if (p.extra) {
-                    const f32x4 ev = *reinterpret_cast<const f32x4*>(p.extra + grow * p.lde + col);
-                    v += ev;
-                }
-                *reinterpret_cast<f32x4*>(p.C + grow * p.ldc + col) = v;
-            }
-            if (p.part) {
-                // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
-                // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
-                // deviations) of its slice with DPP row reductions and the consumer merges the slices exactly
-                // (Chan et al.), which spares a separate read pass over the activation.
-                const bool valid = lrow < seg_rows && col_ok;
-                const int nv = min(WTN, N - (n0 + wn * WTN));                 // valid columns of this slice (uniform)
-                float ps = valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
-                ps = group_sum<LPR>(ps);
-                const float pm = ps / (float)max(nv, 1);
-                float pq = 0.f;
-                if (valid) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { const float d = v[c] - pm; pq += d * d; }
-                }
-                pq = group_sum<LPR>(pq);
-                if ((lane % LPR) == 0) wpart[32 * i + rr] = make_float2(pm, pq);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
-    }
-    if (p.part) {
-        // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int nv = min(WTN, N - (n0 + wn * WTN));
-        for (int r = lane; r < WTM; r += 64) {
-            const int lrow = m0 + wm * WTM + r;
-            if (lrow < seg_rows && nv > 0)
-                p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
-        }
-    }
+    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
 // ------------------------------------------------------------------------------------------------
