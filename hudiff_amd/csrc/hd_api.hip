@@ -183,9 +183,6 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
     *out = nullptr;
     if (cfg->abi_version != HD_ABI_VERSION)
         return fail(HD_ERR_INVALID, "hd_create: abi_version %d != %d", cfg->abi_version, HD_ABI_VERSION);
-    int ndev = hd_device_count();
-    if (ndev <= 0) return fail(HD_ERR_NO_DEVICE, "hd_create: no HIP device visible (this library has no CPU path)");
-    if (device < 0 || device >= ndev) return fail(HD_ERR_INVALID, "hd_create: device %d out of range [0,%d)", device, ndev);
     const HdConfig& c = *cfg;
     if (c.kind != HD_KIND_ANTIBODY && c.kind != HD_KIND_NANOBODY) return fail(HD_ERR_INVALID, "hd_create: kind %d", c.kind);
     if (c.att_model != c.nhead * ATT_HD)
@@ -210,6 +207,10 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
     for (int a : {c.enc_act, c.conv_act})
         if (a != HD_ACT_RELU && a != HD_ACT_GELU) return fail(HD_ERR_INVALID, "hd_create: activation %d", a);
 
+    // the configuration is validated first so that a bad one is reported as such even on a machine without a GPU
+    int ndev = hd_device_count();
+    if (ndev <= 0) return fail(HD_ERR_NO_DEVICE, "hd_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(HD_ERR_INVALID, "hd_create: device %d out of range [0,%d)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));

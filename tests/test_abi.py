@@ -45,6 +45,42 @@ def test_no_cpu_fallback():
     assert e.value.status == HD_ERR_NO_DEVICE
 
 
+def test_config_validation_needs_no_gpu():
+    """hd_create checks the configuration before it looks for a device, so these fail the same way everywhere."""
+    import ctypes as C
+    from hudiff_amd import _lib
+    from hudiff_amd import synthetic as S
+    lib = _lib.load()
+
+    def create(**over):
+        cfg = dict(S.AB_CONFIG, **over)
+        c = _lib.HdConfig()
+        c.abi_version = over.get("abi_version", _lib.HD_ABI_VERSION)
+        c.kind = over.get("kind", _lib.HD_KIND_ANTIBODY)
+        c.n_tokens, c.max_len, c.h_len = cfg["n_tokens"], cfg["max_len"], over.get("h_len", 152)
+        c.d_model, c.sum_d_model = cfg["d_model"], cfg["sum_d_model"]
+        c.n_encoder_layers, c.dual_layers, c.kernel_size, c.r = 6, 6, cfg["aa_kernel_size"], 128
+        c.att_model, c.nhead, c.dim_feedforward, c.cs_layers = cfg["att_model"], cfg["nhead"], 256, 5
+        c.n_region, c.r_embedding, c.n_side, c.s_embedding = 7, 4, 3, 4
+        c.enc_act, c.conv_act, c.dropout = over.get("enc_act", _lib.HD_ACT_GELU), _lib.HD_ACT_RELU, cfg["dropout"]
+        h = C.c_void_p()
+        st = lib.hd_create(C.byref(c), 0, C.byref(h))
+        if st == _lib.HD_OK:
+            lib.hd_destroy(h)
+        return st, lib.hd_last_error().decode()
+
+    assert create(abi_version=99)[0] == _lib.HD_ERR_INVALID
+    assert create(kind=7)[0] == _lib.HD_ERR_INVALID
+    st, msg = create(nhead=4)                       # head dim 128
+    assert st == _lib.HD_ERR_UNSUPPORTED and "head dim" in msg
+    assert create(max_len=400)[0] == _lib.HD_ERR_UNSUPPORTED           # attention kernels are instantiated for <= 304 / <= 160 slots
+    assert create(sum_d_model=512)[0] == _lib.HD_ERR_INVALID          # antibody needs 3 * d_model
+    assert create(dropout=1.5)[0] == _lib.HD_ERR_INVALID
+    assert create(enc_act=9)[0] == _lib.HD_ERR_INVALID
+    assert create(aa_kernel_size=9)[0] == _lib.HD_ERR_UNSUPPORTED
+    assert create()[0] in (_lib.HD_OK, _lib.HD_ERR_NO_DEVICE)          # a valid config only fails for lack of a GPU
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "hudiff_amd")
     for dirpath, _, files in os.walk(pkg):
