@@ -5,7 +5,8 @@ log-dir naming, ``sample_humanization_result.csv`` with header 'Specific,name,hs
     python -m hudiff_amd.cli.nanosample --ckpt hudiffnb.pt --model finetune_vh --inpaint_sample True ...
 
 See hudiff_amd/cli/sample.py for the (forced) differences; additionally the reference re-samples when
-``abnumber.Chain(seq)`` fails to parse (nanosample.py:331-353) -- without abnumber every sample is accepted.
+``abnumber.Chain(seq)`` fails to parse (nanosample.py:331-353) -- without abnumber the built-in slotter's
+domain check (hudiff_amd/numbering.py ``is_variable_domain``) takes its place.
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ from .. import dist as D
 from .. import inputs as I
 from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
 from ..model import NanoAntiTFNet
-from ..sampler import Job, sample_jobs, seed_all
+from ..sampler import Job, sample_jobs_with_retry, seed_all
 from .common import get_logger, get_new_log_dir, load_numbered, write_fasta_wrapped
 
 
@@ -39,6 +40,7 @@ def build_parser():
     p.add_argument("--structure", type=eval, default=False)
     # additions
     p.add_argument("--numbered_fpath", type=str, default=None)
+    p.add_argument("--numbering", choices=["auto", "anarci", "builtin"], default="auto")
     p.add_argument("--device_batch", type=int, default=256)
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     p.add_argument("--device", type=int, default=None)
@@ -52,11 +54,13 @@ def sample_tag(args):
 
 
 def chain_is_valid(seq):
-    """nanosample.py:342 -- ``Chain(g_h, scheme='imgt')`` must parse; True when abnumber is unavailable."""
+    """nanosample.py:342 -- ``Chain(g_h, scheme='imgt')`` must parse; without abnumber the built-in slotter must
+    find a complete heavy domain (both cysteines, Trp41, J motif)."""
     try:
         from abnumber import Chain
     except ImportError:
-        return True
+        from ..numbering import is_variable_domain
+        return is_variable_domain(seq, "H")
     try:
         Chain(seq, scheme="imgt")
         return True
@@ -90,17 +94,21 @@ def main(argv=None):
         raise ValueError(f"{args.numbered_fpath}: {len(numbered)} rows for {len(nano_df.index)} input rows")
     jobs = []
     for idx, line in enumerate(nano_df.itertuples()):
-        h_dict = numbered[idx]["h"] if numbered is not None else I.number_sequence(line.vhhseq)[0]
+        h_dict = numbered[idx]["h"] if numbered is not None else I.number_sequence(line.vhhseq, args.numbering)[0]
         tok, reg, loc = I.nanobody_row(h_dict, inpaint_sample=args.inpaint_sample)
         if args.sample_order == "shuffle":
             np.random.shuffle(loc)                                            # nanosample.py:314-315
         jobs.append(Job(tokens=tok, region=reg, loc=loc, name=str(idx), parent={"h": line.vhhseq}))
 
-    # nanosample.py:316-353: every pass re-sweeps the (already filled) tokens; a pass is needed whenever fewer
-    # than sample_number parseable sequences have been written and tries remain
-    passes = max(1, min(args.try_number, -(-args.sample_number // args.batch_size)))
-    result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
-                         dropout=args.dropout)
+    # nanosample.py:316-353: accept / re-sweep loop (a sample must parse as a heavy domain; the last try is
+    # written regardless), run for all sequences at once
+    def rejected(job, row):
+        if rank == 0:
+            logger.info(I.untokenize_nanobody(row))
+            logger.info("Need to re sample again.")
+    written = sample_jobs_with_retry(model, jobs, args.batch_size, args.seed, want=args.sample_number,
+                                     tries=args.try_number, accept=lambda row: chain_is_valid(I.untokenize_nanobody(row)),
+                                     device_batch=args.device_batch, dropout=args.dropout, log=rejected)
     if rank != 0:
         return None
     save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")
@@ -109,20 +117,11 @@ def main(argv=None):
         f.write("Specific,name,hseq,\n")
         for j, job in enumerate(jobs):
             f.write(f"nano,{job.name},{job.parent['h']}\n")
-            left, tries = args.sample_number, args.try_number
-            for p in range(passes):
-                for r in range(args.batch_size):
-                    if left == 0:
-                        break
-                    g_h = I.untokenize_nanobody(result[j, p, r])
-                    logger.info(g_h)
-                    if chain_is_valid(g_h) or tries == 1:
-                        f.write(f"humanization,{job.name}human_sample,{g_h}\n")
-                        human.append(g_h)
-                        left -= 1 if chain_is_valid(g_h) else 0
-                    else:
-                        logger.info("Need to re sample again.")
-                    tries -= 1
+            for row in written[j]:
+                g_h = I.untokenize_nanobody(row)
+                logger.info(g_h)
+                f.write(f"humanization,{job.name}human_sample,{g_h}\n")
+                human.append(g_h)
     fasta = os.path.join(log_dir, "sample_identity.fa")
     logger.info("Save fasta fpath: {}".format(fasta))
     write_fasta_wrapped([(f"VH{args.fa_version}_{i}", "<unknown description>", s) for i, s in enumerate(human)], fasta)

@@ -5,8 +5,9 @@ row, 'mouse,{name},{h},{l}' followed by 'humanization,{name}human_sample,{h},{l}
     python -m hudiff_amd.cli.sample --ckpt checkpoints/antibody/hudiffab.pt --data_fpath data.csv [...]
     torchrun --nproc-per-node 8 -m hudiff_amd.cli.sample ...          # rows sharded over the node's GPUs
 
-Differences, all forced by what is absent offline: IMGT numbering needs anarci/abnumber,
-so ``--numbered_fpath`` accepts pre-numbered residues; ``--sample_method inpaint`` and
+Differences, all forced by what is absent offline: IMGT numbering uses anarci/abnumber when
+importable and otherwise the built-in slotter (``--numbering``; ``--numbered_fpath`` accepts pre-numbered
+residues); ``--sample_method inpaint`` and
 ``--traditional_method`` (abnumber CDR grafting) are not part of the hot path and raise; the similarity
 search scores identity over the aligned IMGT slots instead of an abnumber alignment; noise comes from the
 library's counter-based generator keyed by (seed, global row, step), not torch's global mt19937 stream.
@@ -48,6 +49,9 @@ def build_parser():
     # additions
     p.add_argument("--numbered_fpath", type=str, default=None,
                    help="JSON-lines file with pre-numbered IMGT residues, one object per mouse row of --data_fpath")
+    p.add_argument("--numbering", choices=["auto", "anarci", "builtin"], default="auto",
+                   help="IMGT numbering of raw sequences: anarci+abnumber as the reference (auto: when importable), "
+                        "else the built-in slotter hudiff_amd/numbering.py")
     p.add_argument("--device_batch", type=int, default=256, help="rows per device launch")
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful",
                    help="faithful = the reference's inference-time dropout (active iff config.dropout > 0)")
@@ -112,14 +116,16 @@ def main(argv=None):
     pad_region = 7 if n_region > 7 else 0                                   # sample.py:462-465
 
     mouse_df = read_mouse_rows(args.data_fpath)
+    if rank == 0 and not args.numbered_fpath:
+        logger.info("IMGT numbering backend: {}".format(I.numbering_backend(args.numbering)))
     numbered = load_numbered(args.numbered_fpath) if args.numbered_fpath else None
     if numbered is not None and len(numbered) != len(mouse_df.index):
         raise ValueError(f"{args.numbered_fpath}: {len(numbered)} rows for {len(mouse_df.index)} mouse rows")
     jobs = []
     for idx, line in enumerate(mouse_df.itertuples()):
         if numbered is None:
-            h_dict, h_type = I.number_sequence(line.h_seq)
-            l_dict, l_type = I.number_sequence(line.l_seq)
+            h_dict, h_type = I.number_sequence(line.h_seq, args.numbering)
+            l_dict, l_type = I.number_sequence(line.l_seq, args.numbering)
         else:
             h_dict, l_dict, l_type = numbered[idx]["h"], numbered[idx]["l"], numbered[idx].get("l_chain", "K")
         tok, reg, chain, loc = I.antibody_row(h_dict, l_dict, l_type, finetune=finetune, pad_region=pad_region)
@@ -132,8 +138,12 @@ def main(argv=None):
     # sample.py:499-538: with similarity search one pass gives the single output row; without it the loop
     # re-sweeps until sample_number rows have been written (batch_size rows per pass)
     passes = 1 if args.similarity_search else max(1, -(-args.sample_number // args.batch_size))
-    result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
-                         dropout=args.dropout)
+    if args.sample_number <= 0 or args.try_number <= 0:            # `while sample_number > 0 and try_num > 0` never runs
+        args.sample_number = 0
+        result = np.zeros((len(jobs), 0, args.batch_size, model.max_len), np.int32)
+    else:
+        result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
+                             dropout=args.dropout)
     if rank != 0:
         return None
 
@@ -153,7 +163,7 @@ def main(argv=None):
                 human_rows.append((g_h, g_l))
             else:
                 left = args.sample_number
-                for p in range(passes):
+                for p in range(result.shape[1]):
                     for r in range(args.batch_size):
                         if left == 0:
                             break

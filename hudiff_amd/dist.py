@@ -45,8 +45,9 @@ def init_process_group(backend: Optional[str] = None):
     return dist
 
 
-def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int) -> Optional[np.ndarray]:
-    """Gather every rank's [rows_r, L] int32 block on rank 0 -> [n_rows, L] (None on other ranks).
+def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int, all_ranks: bool = False) -> Optional[np.ndarray]:
+    """Gather every rank's [rows_r, L] int32 block on rank 0 -> [n_rows, L] (None on other ranks; with
+    ``all_ranks`` an all-gather, for host logic that must take the same decision everywhere).
     Blocks may differ by one row; they are padded to the largest block for the collective."""
     rank, world, local_rank = env_rank_world()
     if world == 1:
@@ -59,10 +60,14 @@ def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int) -> Optional[np.nd
     buf = torch.zeros((cap, L), dtype=torch.int32, device=dev)
     mine = torch.from_numpy(np.ascontiguousarray(local_tokens, dtype=np.int32).reshape(-1, L))
     buf[: mine.shape[0]] = mine.to(dev)
-    outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, outs, dst=0)
-    if rank != 0:
-        return None
+    if all_ranks:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, outs, dst=0)
+        if rank != 0:
+            return None
     parts = []
     for r, o in enumerate(outs):
         lo, hi = shard_bounds(n_rows, r, world)

@@ -5,7 +5,7 @@ Mirrors (reference file:line) ``get_input_element`` / ``batch_input_element``
 from the point AFTER numbering: the hot path starts from int arrays.  Numbering itself
 (``get_pad_seq``: anarci.number + abnumber.Chain, sample.py:78-90) is the "next" row §8f-1; when
 ``abnumber``/``anarci`` are importable ``number_sequence`` uses them exactly as the reference does,
-otherwise callers must supply pre-numbered residues.
+otherwise the built-in slotter (hudiff_amd/numbering.py) or pre-numbered residues supplied by the caller.
 """
 from __future__ import annotations
 
@@ -20,14 +20,32 @@ from .tokenizer import Tokenizer
 _TK = Tokenizer()
 
 
-def number_sequence(aa_seq: str) -> Tuple[Dict[str, str], str]:
-    """sample.py:78-90 -- needs the reference's own third-party stack (ANARCI + HMMER, abnumber)."""
+def numbering_backend(choice: str = "auto") -> str:
+    """'anarci' (the reference's own stack) when importable, else 'builtin' (hudiff_amd/numbering.py)."""
+    if choice in ("anarci", "builtin"):
+        return choice
+    try:
+        import anarci      # noqa: F401
+        import abnumber    # noqa: F401
+        return "anarci"
+    except ImportError:
+        return "builtin"
+
+
+def number_sequence(aa_seq: str, backend: str = "auto") -> Tuple[Dict[str, str], str]:
+    """sample.py:78-90 ``get_pad_seq``: raw sequence -> ({IMGT position: residue}, chain type 'H'|'K'|'L').
+
+    backend 'anarci' runs the reference's third-party stack (ANARCI + HMMER, abnumber) exactly as the
+    reference does; 'builtin' is the dependency-free slotter of hudiff_amd/numbering.py (parity with ANARCI
+    unpinned); 'auto' prefers anarci when it is importable."""
+    if numbering_backend(backend) == "builtin":
+        from .numbering import number_sequence_builtin
+        return number_sequence_builtin(aa_seq)
     try:
         from anarci import number
         from abnumber import Chain
     except ImportError as e:
-        raise RuntimeError("IMGT numbering needs `anarci` and `abnumber` (not installed here); pass "
-                           "pre-numbered sequences instead (see INTEGRATION.md)") from e
+        raise RuntimeError("--numbering anarci needs `anarci` and `abnumber` (not installed here)") from e
     seq_dict = {}
     results = number(aa_seq, scheme="imgt")
     for key, value in results[0]:

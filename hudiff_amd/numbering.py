@@ -1,0 +1,333 @@
+"""Built-in IMGT slotter: raw VH / VK / VL / VHH sequence -> {IMGT position: residue} + chain type.
+
+SURVEY.md §8f rank 1 -- the step immediately in front of the sampling path.  The reference calls
+``anarci.number(seq, scheme='imgt')`` and ``abnumber.Chain(seq).chain_type`` (antibody_scripts/sample.py:78-90,
+nanobody_scripts/nanosample.py:75-88); both need ANARCI + HMMER + germline HMMs, none of which exist on an
+offline MI355X box.  This module gives the CLIs a numbering front-end that needs nothing but numpy, with the
+same output contract (``{'1': 'E', ..., '111A': 'G', ...}``, chain type 'H' | 'K' | 'L').
+
+PARITY UNPINNED against ANARCI (it cannot be run here).  What is pinned (tests/test_numbering.py): the
+published CDR-IMGT delimitations of well-known therapeutic antibodies, and the structural invariants of the
+IMGT unique numbering (Lefranc et al. 2003: 1st-CYS 23, CONSERVED-TRP 41, 2nd-CYS 104, J-motif [FW]118-G119-x-G121)
+on every sequence of the evaluation sets.  ``hudiff_amd.inputs.number_sequence`` prefers anarci/abnumber
+whenever they are importable.
+
+Method.  A variable domain is four framework stretches with fixed IMGT columns (FR1 1-26, FR2 39-55,
+FR3 66-104, FR4 118-128 / 118-127) separated by three loops of free length.  The query is aligned to that
+chain of framework columns by an integer Viterbi pass (match = best BLOSUM62 score against the residues
+that germline genes of the chain class show at the column; deleting a column is cheap only where germlines
+themselves have an IMGT gap -- 10, 73, 81, 82 --; loop residues are free), once per chain class; the best class
+wins.  Loop residues then receive their positions by the IMGT rule: fill from both ends towards the
+middle, the odd residue on the N-terminal side, CDR3 insertions alternate 112A, 111A, 112B, 111B, ...
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+_AA = "ARNDCQEGHILKMFPSTWYV"
+_AA_IDX = {a: i for i, a in enumerate(_AA)}
+# BLOSUM62 (Henikoff & Henikoff 1992), rows/columns in the order of _AA
+_BLOSUM62 = np.array([int(v) for v in """
+ 4 -1 -2 -2  0 -1 -1  0 -2 -1 -1 -1 -1 -2 -1  1  0 -3 -2  0
+-1  5  0 -2 -3  1  0 -2  0 -3 -2  2 -1 -3 -2 -1 -1 -3 -2 -3
+-2  0  6  1 -3  0  0  0  1 -3 -3  0 -2 -3 -2  1  0 -4 -2 -3
+-2 -2  1  6 -3  0  2 -1 -1 -3 -4 -1 -3 -3 -1  0 -1 -4 -3 -3
+ 0 -3 -3 -3  9 -3 -4 -3 -3 -1 -1 -3 -1 -2 -3 -1 -1 -2 -2 -1
+-1  1  0  0 -3  5  2 -2  0 -3 -2  1  0 -3 -1  0 -1 -2 -1 -2
+-1  0  0  2 -4  2  5 -2  0 -3 -3  1 -2 -3 -1  0 -1 -3 -2 -2
+ 0 -2  0 -1 -3 -2 -2  6 -2 -4 -4 -2 -3 -3 -2  0 -2 -2 -3 -3
+-2  0  1 -1 -3  0  0 -2  8 -3 -3 -1 -2 -1 -2 -1 -2 -2  2 -3
+-1 -3 -3 -3 -1 -3 -3 -4 -3  4  2 -3  1  0 -3 -2 -1 -3 -1  3
+-1 -2 -3 -4 -1 -2 -3 -4 -3  2  4 -2  2  0 -3 -2 -1 -2 -1  1
+-1  2  0 -1 -3  1  1 -2 -1 -3 -2  5 -1 -3 -1  0 -1 -3 -2 -2
+-1 -1 -2 -3 -1  0 -2 -3 -2  1  2 -1  5  0 -2 -1 -1 -1 -1  1
+-2 -3 -3 -3 -2 -3 -3 -3 -1  0  0 -3  0  6 -4 -2 -2  1  3 -1
+-1 -2 -2 -1 -3 -1 -1 -2 -2 -3 -3 -1 -2 -4  7 -1 -1 -4 -3 -2
+ 1 -1  1  0 -1  0  0  0 -1 -2 -2  0 -1 -2 -1  4  1 -3 -2 -2
+ 0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  1  5 -2 -2  0
+-3 -3 -4 -4 -2 -2 -3 -2 -2 -3 -2 -3 -1  1 -4 -3 -2 11  2 -3
+-2 -2 -2 -3 -2 -1 -2 -3  2 -1 -1 -2 -1  3 -3 -2 -2  2  7 -1
+ 0 -3 -3 -3 -1 -2 -2 -3 -3  3  1 -2  1 -1 -2 -2  0 -3 -1  4
+""".split()], dtype=np.int32).reshape(20, 20)
+
+# Germline-like framework templates in IMGT-gapped form, "FR1 FR2 FR3" = 26 + 17 + 39 columns ('.' = IMGT gap).
+# Representative human, mouse and camelid V genes per chain class; only the frameworks are used.
+_V_TEMPLATES = {
+    "H": """
+QVQLVQSGA.EVKKPGSSVKVSCKAS ISWVRQAPGQGLEWMGG NYAQKFQ.GRVTITADESTSTAYMELSSLRSEDTAVYYC
+QVQLVQSGA.EVKKPGASVKVSCKAS MHWVRQAPGQGLEWMGW NYAQKFQ.GRVTMTRDTSISTAYMELSRLRSDDTAVYYC
+QVQLVQSGS.ELKKPGASVKVSCKAS MNWVRQAPGQGLEWMGW TYAQGFT.GRFVFSLDTSVSTAYLQISSLKAEDTAVYYC
+QITLKESGP.TLVKPTQTLTLTCTFS VGWIRQPPGKALEWLAL RYSPSLK.SRLTITKDTSKNQVVLTMTNMDPVDTATYYC
+EVQLLESGG.GLVQPGGSLRLSCAAS MSWVRQAPGKGLEWVSA YYADSVK.GRFTISRDNSKNTLYLQMNSLRAEDTAVYYC
+QVQLVESGG.GVVQPGRSLRLSCAAS MHWVRQAPGKGLEWVAV YYADSVK.GRFTISRDNSKNTLYLQMNSLRAEDTAVYYC
+EVQLVESGG.GLVKPGGSLRLSCAAS MSWVRQAPGKGLEWVGR DYAAPVK.GRFTISRDDSKNTLYLQMNSLKTEDTAVYYC
+EVQLVESGG.GLVQPGGSLRLSCAAS MSWVRQAPGKGLEWVAN YYVDSVK.GRFTISRDNAKNSLYLQMNSLRAEDTAVYYC
+QVQLQQWGA.GLLKPSETLSLTCAVY WSWIRQPPGKGLEWIGE NYNPSLK.SRVTISVDTSKNQFSLKLSSVTAADTAVYYC
+QLQLQESGP.GLVKPSETLSLTCTVS WGWIRQPPGKGLEWIGS YYNPSLK.SRVTISVDTSKNQFSLKLSSVTAADTAVYYC
+EVQLVQSGA.EVKKPGESLKISCKGS IGWVRQMPGKGLEWMGI RYSPSFQ.GQVTISADKSISTAYLQWSSLKASDTAMYYC
+QVQLQQSGP.GLVKPSQTLSLTCAIS WNWIRQSPSRGLEWLGR DYAVSVK.SRITINPDTSKNQFSLQLNSVTPEDTAVYYC
+QVQLQQSGA.ELVRPGASVKLSCKAS MNWVKQRPEQGLEWIGR HYNQKFK.DKAILTVDKSSSTAYMQLSSLTSEDSAVYYC
+QVQLQQPGA.ELVKPGASVKMSCKAS MHWVKQTPGRGLEWIGA SYNQKFK.GKATLTADKSSSTAYMQLSSLTSEDSAVYYC
+EVKLVESGG.GLVKPGGSLKLSCAAS MSWVRQTPEKRLEWVAT YYPDSVK.GRFTISRDNAKNTLYLQMSSLRSEDTAMYYC
+QVQLKESGP.GLVAPSQSLSITCTVS VHWVRQPPGKGLEWLGV NYNSALM.SRLSISKDNSKSQVFLKMNSLQTDDTAMYYC
+DVQLQESGP.GLVKPSQSLSLTCTVT WNWIRQFPGNKLEWMGY SYNPSLK.SRISITRDTSKNQFFLQLNSVTTEDTATYYC
+EVQLQQSGA.ELVKPGASVKLSCTAS MHWVKQRPEQGLEWIGR KYDPKFQ.GKATITADTSSNTAYLQLSSLTSEDTAVYYC
+QIQLVQSGP.ELKKPGETVKISCKAS MNWVKQAPGKGLKWMGW TYADDFK.GRFAFSLETSASTAYLQINNLKNEDTATYFC
+EVKLEESGG.GLVQPGGSMKLSCVAS MNWVRQSPEKGLEWVAE HYAESVK.GRFTISRDDSKSSVYLQMNNLRAEDTGIYYC
+EVQLQQSGP.ELVKPGASVKISCKAS MNWVKQSHGKSLEWIGD SYNQKFK.GKATLTVDKSSSTAYMELRSLTSEDSAVYYC
+QVQLVESGG.GLVQAGGSLRLSCAAS MGWFRQAPGKEREFVAA YYADSVK.GRFTISRDNAKNTVYLQMNSLKPEDTAVYYC
+QVQLQESGG.GSVQAGGSLRLSCAAS MGWFRQAPGKEREGVAA YYADSVK.GRFTISQDNAKNTVYLQMNSLKPEDTAMYYC
+EVQLVESGG.GLVQPGGSLRLSCAAS MSWVRQAPGKGLEWVSA NYADSVK.GRFTISRDNAKNTLYLQMNSLKPEDTALYYC
+""",
+    "K": """
+DIQMTQSPSSLSASVGDRVTITCRAS LNWYQQKPGKAPKLLIY SLQSGVP.SRFSGSG..SGTDFTLTISSLQPEDFATYYC
+DIQMTQSPSTLSASVGDRVTITCRAS LAWYQQKPGKAPKLLIY SLESGVP.SRFSGSG..SGTEFTLTISSLQPDDFATYYC
+EIVLTQSPGTLSLSPGERATLSCRAS LAWYQQKPGQAPRLLIY SRATGIP.DRFSGSG..SGTDFTLTISRLEPEDFAVYYC
+EIVLTQSPATLSLSPGERATLSCRAS LAWYQQKPGQAPRLLIY NRATGIP.ARFSGSG..SGTDFTLTISSLEPEDFAVYYC
+DIVMTQSPDSLAVSLGERATINCKSS LAWYQQKPGQPPKLLIY TRESGVP.DRFSGSG..SGTDFTLTISSLQAEDVAVYYC
+DIVMTQSPLSLPVTPGEPASISCRSS LDWYLQKPGQSPQLLIY NRASGVP.DRFSGSG..SGTDFTLKISRVEAEDVGVYYC
+DVVMTQSPLSLPVTLGQPASISCRSS LNWFQQRPGQSPRRLIY NRDSGVP.DRFSGSG..SGTDFTLKISRVEAEDVGVYYC
+DIVMTQSHKFMSTSVGDRVSITCKAS VAWYQQKPGQSPKLLIY YRYTGVP.DRFTGSG..SGTDFTFTISSVQAEDLAVYYC
+DIVLTQSPASLAVSLGQRATISCRAS MHWYQQKPGQPPKLLIY NLESGIP.ARFSGSG..SRTDFTLTINPVEADDVATYYC
+QIVLTQSPAIMSASPGEKVTMTCSAS MHWYQQKSGTSPKRWIY KLASGVP.ARFSGSG..SGTSYSLTISSMEAEDAATYYC
+DVVMTQTPLSLPVSLGDQASISCRSS LHWYLQKPGQSPKLLIY NRFSGVP.DRFSGSG..SGTDFTLKISRVEAEDLGVYFC
+DIQMTQTTSSLSASLGDRVTISCRAS LNWYQQKPDGTVKLLIY RLHSGVP.SRFSGSG..SGTDYSLTISNLEQEDIATYFC
+DIKMTQSPSSMYASLGERVTITCKAS LSWFQQKPGKSPKTLIY RLVDGVP.SRFSGSG..SGQDYSLTISSLEYEDMGIYYC
+DIVMTQAAPSVPVTPGESVSISCRSS LYWFLQRPGQSPQLLIY NLASGVP.DRFSGSG..SGTAFTLRISRVEAEDVGVYYC
+NIVMTQSPKSMSMSVGERVTLSCKAS VSWYQQKPEQSPKLLIY NRYTGVP.DRFTGSG..SATDFTLTISSVQAEDLADYHC
+""",
+    "L": """
+QSVLTQPPS.VSGAPGQRVTISCTGS VHWYQQLPGTAPKLLIY NRPSGVP.DRFSGSK..SGTSASLAITGLQAEDEADYYC
+QSVLTQPPS.ASGTPGQRVTISCSGS VNWYQQLPGTAPKLLIY QRPSGVP.DRFSGSK..SGTSASLAISGLQSEDEADYYC
+QSALTQPAS.VSGSPGQSITISCTGT VSWYQQHPGKAPKLMIY NRPSGVS.NRFSGSK..SGNTASLTISGLQAEDEADYYC
+QSALTQPRS.VSGSPGQSVTISCTGT VSWYQQHPGKAPKLMIY KRPSGVP.DRFSGSK..SGNTASLTISGLQAEDEADYYC
+SYVLTQPPS.VSVAPGKTARITCGGN VHWYQQKPGQAPVLVIY DRPSGIP.ERFSGSN..SGNTATLTISRVEAGDEADYYC
+SYELTQPPS.VSVSPGQTASITCSGD ACWYQQKPGQSPVLVIY KRPSGIP.ERFSGSN..SGNTATLTISGTQAMDEADYYC
+SSELTQDPA.VSVALGQTVRITCQGD ASWYQQKPGQAPVLVIY NRPSGIP.DRFSGSS..SGNTASLTITGAQAEDEADYYC
+NFMLTQPHS.VSESPGKTVTISCTRS VQWYQQRPGSSPTTVIY QRPSGVP.DRFSGSIDSSSNSASLTISGLKTEDEADYYC
+QTVVTQEPS.FSVSPGGTVTLTCGLS PSWYQQTPGQAPRTLIY TRSSGVP.DRFSGSI..LGNKAALTITGAQADDESDYYC
+QAVVTQESA.LTTSPGETVTLTCRSS ANWVQEKPDHLFTGLIG NRAPGVP.ARFSGSL..IGDKAALTITGAQTEDEAIYFC
+QLVLTQSSS.ASFSLGASAKLTCTLS IEWYQQQPLKPPKYVME SKGDGIP.DRFSGSS..SGADRYLSISNIQPEDEAIYIC
+""",
+}
+_J_TEMPLATES = {
+    "H": "WGQGTLVTVSS WGQGTTVTVSS WGQGTMVTVSS WGRGTLVTVSS WGAGTTVTVSS WGQGTSVTVSS WGQGTLVTVSA WGQGTQVTVSS "
+         "WGKGTQVTVSS WGKGTTVTVSS",
+    "K": "FGQGTKVEIK FGGGTKLEIK FGPGTKVDIK FGSGTKLEIK FGAGTKLELK FGQGTRLEIK FGGGTKVEIK FGQGTKLEIK",
+    "L": "FGGGTKLTVL FGTGTKVTVL FGSGTKVTVL FGGGTQLTVL FGEGTELTVL FGGGTKVTVL",
+}
+
+_FR_COLUMNS = list(range(1, 27)) + list(range(39, 56)) + list(range(66, 105))      # the 82 V framework columns
+_ANCHORS = {23: "C", 41: "W", 104: "C", 118: "WF", 119: "G", 121: "G"}
+_ANCHOR_BONUS = 6
+_DEL_GERMLINE_GAP = 2      # deleting a column that germline genes leave empty
+_DEL_COLUMN = 12           # deleting any other framework column
+_INSERT = 12               # a residue between two framework columns
+_SKIP_END = 3              # framework columns missing at a truncated N- or C-terminus
+_NEG = -10 ** 6
+_MIN_SCORE = 220           # below this the query is not a variable domain (ANARCI would return no hit)
+
+# CDR loops: (first position, last position) -- IMGT CDR1 27-38, CDR2 56-65, CDR3 105-117
+_LOOPS = {26: (27, 38), 55: (56, 65), 104: (105, 117)}
+
+
+class NumberingError(ValueError):
+    pass
+
+
+def _build_profile(cls: str):
+    """-> nodes [(column | ('loop', first, last))], match scores [n_cols, 21] (last = unknown residue), deletion cost."""
+    v_rows = [t.split() for t in _V_TEMPLATES[cls].strip().splitlines()]
+    j_rows = _J_TEMPLATES[cls].split()
+    for fr1, fr2, fr3 in v_rows:
+        assert (len(fr1), len(fr2), len(fr3)) == (26, 17, 39), (cls, fr1, fr2, fr3)
+    j_len = len(j_rows[0])
+    assert all(len(j) == j_len for j in j_rows)
+    columns = _FR_COLUMNS + list(range(118, 118 + j_len))
+    seen = {c: set() for c in columns}
+    for fr1, fr2, fr3 in v_rows:
+        for c, a in zip(_FR_COLUMNS, fr1 + fr2 + fr3):
+            seen[c].add(a)
+    for j in j_rows:
+        for c, a in zip(range(118, 118 + j_len), j):
+            seen[c].add(a)
+    score = np.full((len(columns), 21), -1, dtype=np.int32)
+    delete = np.zeros(len(columns), dtype=np.int32)
+    for k, c in enumerate(columns):
+        residues = [_AA_IDX[a] for a in seen[c] if a != "."]
+        score[k, :20] = _BLOSUM62[:, residues].max(axis=1) if residues else 0    # never occupied in germlines
+        for a in _ANCHORS.get(c, ""):
+            score[k, _AA_IDX[a]] += _ANCHOR_BONUS
+        delete[k] = _DEL_GERMLINE_GAP if "." in seen[c] else _DEL_COLUMN
+    nodes = []
+    for k, c in enumerate(columns):
+        nodes.append(("col", c, k))
+        if c in _LOOPS:
+            nodes.append(("loop",) + _LOOPS[c])
+    return nodes, score, delete
+
+
+_PROFILES = {cls: _build_profile(cls) for cls in "HKL"}
+
+
+def _scan_insertions(base: np.ndarray) -> np.ndarray:
+    """S[i] = max_{j <= i} base[j] - _INSERT * (i - j)."""
+    ramp = _INSERT * np.arange(base.shape[0], dtype=np.int64)
+    return np.maximum.accumulate(base + ramp) - ramp
+
+
+def _align(q: np.ndarray, cls: str):
+    """Viterbi over the node chain.  -> (score, [(node index, residue index | None)] matched / deleted columns,
+    loop spans, framework insertions)."""
+    nodes, score, delete = _PROFILES[cls]
+    n = q.shape[0]
+    K = len(nodes)
+    S = np.full((K, n + 1), _NEG, dtype=np.int64)
+    prev = np.full(n + 1, _NEG, dtype=np.int64)
+    n_cols_before = 0
+    col_rank = []                                    # framework columns in front of node k
+    for k, node in enumerate(nodes):
+        col_rank.append(n_cols_before)
+        if node[0] == "loop":
+            S[k] = np.maximum.accumulate(prev)
+        else:
+            m = score[node[2], q]                                        # [n] match score of every residue
+            start = -_SKIP_END * n_cols_before                           # alignment starts here, flank is free
+            base = prev - delete[node[2]]
+            base[1:] = np.maximum(base[1:], np.maximum(prev[:-1], start) + m)
+            S[k] = _scan_insertions(base)
+            n_cols_before += 1
+        prev = S[k]
+    total_cols = n_cols_before
+    # end anywhere: remaining framework columns are charged as a truncated C-terminus
+    best, best_k, best_i = _NEG, -1, -1
+    for k, node in enumerate(nodes):
+        if node[0] != "col":
+            continue
+        tail = -_SKIP_END * (total_cols - col_rank[k] - 1)
+        i = int(np.argmax(S[k]))
+        if S[k, i] + tail > best:
+            best, best_k, best_i = int(S[k, i] + tail), k, i
+    # ---- traceback (integer scores: equality identifies the transition taken) --------------------------
+    cols: Dict[int, int] = {}            # IMGT column -> residue index
+    loops: Dict[int, Tuple[int, int]] = {}
+    inserts: List[Tuple[int, int]] = []  # (column it follows, residue index)
+    k, i = best_k, best_i
+    while k >= 0:
+        node = nodes[k]
+        before = S[k - 1] if k > 0 else np.full(n + 1, _NEG, dtype=np.int64)
+        if node[0] == "loop":
+            j = i
+            while before[j] != S[k, i]:
+                j -= 1
+            loops[node[1]] = (j, i)
+            k, i = k - 1, j
+            continue
+        c, kk = node[1], node[2]
+        start = -_SKIP_END * col_rank[k]
+        if i > 0:
+            m = int(score[kk, q[i - 1]])
+            if max(int(before[i - 1]), start) + m == S[k, i]:
+                cols[c] = i - 1
+                if int(before[i - 1]) >= start and k > 0:
+                    k, i = k - 1, i - 1
+                    continue
+                break                                             # the alignment starts at this column
+        if before[i] - delete[kk] == S[k, i]:
+            k = k - 1
+            continue
+        if i > 0 and S[k, i - 1] - _INSERT == S[k, i]:
+            inserts.append((c, i - 1))
+            i -= 1
+            continue
+        raise AssertionError("numbering traceback lost its path")
+    return best, cols, loops, inserts
+
+
+def _loop_positions(length: int, first: int, last: int) -> List[Tuple[int, str]]:
+    """IMGT placement of `length` loop residues on positions first..last (+ insertions when it overflows).
+
+    Ends fill first, alternating N-terminal / C-terminal side, so gaps sit in the middle and an odd residue is
+    on the N-terminal side (CDR1 'GFTFSSYA' -> 27-30, 35-38).  Overflow: insertion letters on the two central
+    positions, alternating C-terminal side first (CDR3: 112A, 111A, 112B, 111B, ...)."""
+    width = last - first + 1
+    n_front = (min(length, width) + 1) // 2
+    n_back = min(length, width) // 2
+    extra = max(0, length - width)
+    mid_lo = first + (width + 1) // 2 - 1              # CDR3: 111 ; CDR1: 32 ; CDR2: 60
+    mid_hi = mid_lo + 1
+    if extra == 0:
+        return [(first + i, "") for i in range(n_front)] + [(last - n_back + 1 + i, "") for i in range(n_back)]
+    letters = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    n_hi = (extra + 1) // 2                            # insertions numbered mid_hi + letter (come first in sequence
+    n_lo = extra // 2                                  # order reversed: 112B, 112A, 112)
+    if max(n_hi, n_lo) > len(letters):
+        raise NumberingError(f"loop of {length} residues is too long to number")
+    out = [(first + i, "") for i in range(mid_lo - first + 1)]
+    out += [(mid_lo, letters[i]) for i in range(n_lo)]
+    out += [(mid_hi, letters[i]) for i in reversed(range(n_hi))]
+    out += [(mid_hi + i, "") for i in range(last - mid_hi + 1)]
+    return out
+
+
+def _encode(seq: str) -> np.ndarray:
+    return np.array([_AA_IDX.get(a, 20) for a in seq], dtype=np.int64)
+
+
+def number_imgt(aa_seq: str, allowed: str = "HKL"):
+    """-> ([((position, insertion code), residue)], chain type) in the shape ``anarci.number`` returns
+    (positions without a residue carry '-'), chain type 'H' | 'K' | 'L'."""
+    seq = aa_seq.strip().upper()
+    if not seq:
+        raise NumberingError("empty sequence")
+    q = _encode(seq)
+    results = {cls: _align(q, cls) for cls in allowed}
+    cls = max(allowed, key=lambda c: results[c][0])
+    score, cols, loops, inserts = results[cls]
+    if score < _MIN_SCORE:
+        raise NumberingError(f"no antibody variable domain found (best score {score} < {_MIN_SCORE})")
+    last = 128 if cls == "H" else 127
+    placed: Dict[Tuple[int, str], str] = {}
+    for c, i in cols.items():
+        placed[(c, "")] = seq[i]
+    by_col: Dict[int, List[int]] = {}
+    for c, i in inserts:
+        by_col.setdefault(c, []).append(i)
+    for c, idx in by_col.items():
+        for n_ins, i in enumerate(sorted(idx)):
+            placed[(c, "ABCDEFGHIJKLMNOPQRSTUVWXYZ"[min(n_ins, 25)])] = seq[i]
+    for first, (j, i) in loops.items():
+        end = {27: 38, 56: 65, 105: 117}[first]
+        for (pos, ins), a in zip(_loop_positions(i - j, first, end), seq[j:i]):
+            placed[(pos, ins)] = a
+    for pos in range(1, last + 1):
+        placed.setdefault((pos, ""), "-")
+
+    def order(key):
+        pos, ins = key
+        # 112 insertions run backwards in sequence order (112B, 112A, 112); so do the C-terminal halves of
+        # overflowing CDR1 / CDR2 loops (33B, 33A, 33 / 61B, 61A, 61)
+        if ins and pos in (33, 61, 112):
+            return (pos, -ord(ins))
+        return (pos, ord(ins) if ins else (0 if pos not in (33, 61, 112) else 1))
+    numbering = [((pos, ins if ins else " "), placed[(pos, ins)]) for pos, ins in sorted(placed, key=order)]
+    return numbering, cls
+
+
+def number_sequence_builtin(aa_seq: str, allowed: str = "HKL") -> Tuple[Dict[str, str], str]:
+    """Same contract as ``get_pad_seq`` (antibody_scripts/sample.py:78-90)."""
+    numbering, cls = number_imgt(aa_seq, allowed)
+    return {str(pos) + ins.strip(): a for (pos, ins), a in numbering}, cls
+
+
+def is_variable_domain(aa_seq: str, allowed: str = "H") -> bool:
+    """Stand-in for the nanobody sampler's validity check ``Chain(g_h, scheme='imgt')`` (nanosample.py:338-353):
+    the sequence must number as a complete domain with both cysteines, the tryptophan and the J motif."""
+    try:
+        d, _ = number_sequence_builtin(aa_seq, allowed)
+    except NumberingError:
+        return False
+    return d.get("23") == "C" and d.get("104") == "C" and d.get("41") == "W" and d.get("119") == "G" \
+        and d.get("118", "-") != "-" and d.get("121", "-") != "-"

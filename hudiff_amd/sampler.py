@@ -27,7 +27,7 @@ def seed_all(seed: int):
 @dataclass
 class Job:
     """One sequence to humanize: masked tokens, region ids, chain ids (antibody) and its visiting order."""
-    tokens: np.ndarray
+    tokens: np.ndarray                   # [L], or [replicas, L] when replicas continue from different states
     region: np.ndarray
     loc: np.ndarray                      # already shuffled (or not) by the caller
     chain: Optional[tuple] = None        # (heavy id, light id) for antibodies
@@ -36,9 +36,9 @@ class Job:
 
 
 def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes: int = 1,
-                device_batch: int = 256, dropout: str = "faithful", q_noise=None) -> np.ndarray:
+                device_batch: int = 256, dropout: str = "faithful", q_noise=None, all_ranks: bool = False) -> np.ndarray:
     """Sample ``replicas`` rows per job; returns int32 [len(jobs), passes, replicas, L] on rank 0 (every rank
-    when single-process).  ``passes`` > 1 re-runs the loop over the already filled tokens, which is what the
+    when single-process or ``all_ranks``).  ``passes`` > 1 re-runs the loop over the already filled tokens, which is what the
     reference's ``while sample_number > 0`` loop does (sample.py:499, nanosample.py:316)."""
     L = model.max_len
     n_rows = len(jobs) * replicas
@@ -51,7 +51,8 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
         e = min(s + device_batch, hi)
         ids = np.arange(s, e)
         jb = [jobs[i // replicas] for i in ids]
-        tok = np.stack([j.tokens for j in jb]).astype(np.int32)
+        tok = np.stack([j.tokens if np.ndim(j.tokens) == 1 else j.tokens[i % replicas]
+                        for i, j in zip(ids, jb)]).astype(np.int32)
         reg = np.stack([j.region for j in jb]).astype(np.int32)
         order = np.zeros((len(jb), Tmax), np.int32)
         T = np.zeros(len(jb), np.int32)
@@ -63,7 +64,49 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
             tok = model.sample(tok, reg, chain, order, T, seed=seed + 1000003 * p, row0=s, dropout=dropout,
                                q_noise=None if q_noise is None else q_noise[p][:, s:e])
             out[p, s - lo:e - lo] = tok
-    gathered = [D.gather_rows(out[p], n_rows, L) for p in range(passes)]
+    gathered = [D.gather_rows(out[p], n_rows, L, all_ranks) for p in range(passes)]
     if gathered[0] is None:
         return None
     return np.stack(gathered, axis=0).reshape(passes, len(jobs), replicas, L).transpose(1, 0, 2, 3)
+
+
+def sample_jobs_with_retry(model, jobs: Sequence[Job], replicas: int, seed: int, *, want: int, tries: int, accept,
+                           device_batch: int = 256, dropout: str = "faithful", log=None) -> List[List[np.ndarray]]:
+    """The nanobody sampler's accept / re-sweep loop (nanobody_scripts/nanosample.py:316-353), batched.
+
+    Per input sequence the reference keeps ``sample_number`` (rows still wanted) and ``try_num``: while both are
+    positive it sweeps all ``batch_size`` replicas once more (from their current, already filled tokens), then
+    walks the replicas in order: stop when nothing is wanted; an accepted row is written and counted; a rejected
+    row is written only when ``try_num == 1``; ``try_num`` drops by one per row looked at.  Here every sweep runs
+    all still-active sequences as one device batch; the decisions are taken on every rank from all-gathered
+    tokens.  Returns, per job, the rows written, in order."""
+    state = [{"left": want, "tries": tries, "tokens": None, "out": []} for _ in jobs]
+    active = [j for j in range(len(jobs)) if want > 0 and tries > 0]
+    sweep = 0
+    while active:
+        sub = [Job(tokens=jobs[j].tokens if state[j]["tokens"] is None else state[j]["tokens"], region=jobs[j].region,
+                   loc=jobs[j].loc, chain=jobs[j].chain, name=jobs[j].name) for j in active]
+        res = sample_jobs(model, sub, replicas, seed + 1000003 * sweep, device_batch=device_batch, dropout=dropout,
+                          all_ranks=True)
+        still = []
+        for a, j in enumerate(active):
+            st = state[j]
+            st["tokens"] = res[a, 0]
+            for row in res[a, 0]:
+                if st["left"] == 0:
+                    break
+                ok = bool(accept(row))
+                if ok:
+                    st["out"].append(row)
+                    st["left"] -= 1
+                else:
+                    if st["tries"] == 1:
+                        st["out"].append(row)
+                    if log is not None:
+                        log(jobs[j], row)
+                st["tries"] -= 1
+            if st["left"] > 0 and st["tries"] > 0:
+                still.append(j)
+        active = still
+        sweep += 1
+    return [st["out"] for st in state]

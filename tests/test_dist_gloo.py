@@ -22,6 +22,12 @@ if rank == 0:
     np.save(os.environ["HD_OUT"], res)
 else:
     assert res is None
+# accept / re-sweep loop: every rank takes the same decisions from all-gathered rows
+from hudiff_amd.sampler import sample_jobs_with_retry
+jobs = _jobs(5)
+probe = int(jobs[0].loc[0])
+rows = sample_jobs_with_retry(FakeModel(), jobs, 2, 7, want=2, tries=5, accept=lambda r: int(r[probe]) % 3 == 0, device_batch=3)
+np.save(os.environ["HD_OUT"] + f".retry{rank}.npy", np.array([len(r) for r in rows] + [int(np.sum([x.sum() for x in r])) for r in rows]))
 import torch.distributed as dist
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -53,3 +59,10 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = np.load(out)
     assert got.shape == want.shape == (7, 1, 3, 291) and np.array_equal(got, want)
+    from hudiff_amd.sampler import sample_jobs_with_retry
+    jobs = _jobs(5)
+    probe = int(jobs[0].loc[0])
+    rows = sample_jobs_with_retry(FakeModel(), jobs, 2, 7, want=2, tries=5, accept=lambda r: int(r[probe]) % 3 == 0, device_batch=3)
+    single = np.array([len(r) for r in rows] + [int(np.sum([x.sum() for x in r])) for r in rows])
+    for rank in (0, 1):
+        assert np.array_equal(np.load(str(out) + f".retry{rank}.npy"), single)

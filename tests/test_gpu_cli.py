@@ -92,3 +92,73 @@ def test_nanobody_cli_end_to_end(tmp_path):
         assert lines[1 + 2 * i].startswith(f"nano,{i},") and lines[2 + 2 * i].startswith(f"humanization,{i}human_sample,")
     fa = open(os.path.join(os.path.dirname(out), "sample_identity.fa")).read().splitlines()
     assert fa[0] == ">VHv_nano_0 <unknown description>"
+
+
+def test_antibody_cli_from_raw_sequences(tmp_path):
+    """No pre-numbered input: raw VH / VL strings go through the built-in IMGT slotter.  The
+    finetune mask samples framework slots only, so every Kabat CDR (hence every shorter CDR-IMGT core) must come
+    out unchanged, in order."""
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd.cli import sample as cli
+    from test_numbering import KNOWN
+    cfg = dict(load_cfg("ab"), dropout=0.2)
+    sd = {k: torch.from_numpy(v) for k, v in load_weights("ab").items()}
+    ckdir = tmp_path / "run" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    torch.save({"fineconfig": ck.EasyDict({}), "pretrain_config": ck.EasyDict({"name": "trans_oadm", "model": cfg}), "model": sd},
+               ckdir / "hudiffab.pt")
+    pairs = [("trastuzumab", "trastuzumab_VH", "trastuzumab_VK"), ("adalimumab", "adalimumab_VH", "adalimumab_VK"),
+             ("chimera", "pembrolizumab_VH", "avelumab_VL")]
+    csv = tmp_path / "humab_pairs.csv"
+    with open(csv, "w") as f:
+        f.write(",type,name,h_seq,l_seq\n")
+        for i, (name, h, l) in enumerate(pairs):
+            f.write(f"{i},mouse,{name},{KNOWN[h][0]},{KNOWN[l][0]}\n")
+    out = cli.main(["--ckpt", str(ckdir / "hudiffab.pt"), "--data_fpath", str(csv), "--numbering", "builtin",
+                    "--batch_size", "2", "--seed", "11"])
+    assert "_humab_" in os.path.basename(os.path.dirname(out))
+    lines = open(out).read().splitlines()
+    assert len(lines) == 1 + 2 * len(pairs)
+    for i, (name, h, l) in enumerate(pairs):
+        m, s = lines[1 + 2 * i].split(","), lines[2 + 2 * i].split(",")
+        assert m == ["mouse", name, KNOWN[h][0], KNOWN[l][0]] and s[:2] == ["humanization", name + "human_sample"]
+        for chain_seq, key in ((s[2], h), (s[3], l)):
+            pos = 0
+            for cdr in KNOWN[key][2:]:
+                core = cdr[2:] if cdr is KNOWN[key][4] else cdr            # CDR3-IMGT starts 2 before Kabat's
+                pos = chain_seq.index(core[:max(3, len(core) - 3)], pos) + 1
+            assert chain_seq != KNOWN[key][0]                               # frameworks were resampled
+
+
+def test_nanobody_cli_from_raw_sequences(tmp_path):
+    """Raw VHH strings -> built-in slotter -> sampler; with random weights no sample parses as a heavy domain, so
+    every input exhausts its tries and the last sweep is written (nanosample.py:346-349)."""
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd.cli import nanosample as cli
+    from test_numbering import KNOWN
+    cfg = dict(load_cfg("nb"), dropout=0.5)
+    sd = {"infilling_pretrain." + k: torch.from_numpy(v) for k, v in load_weights("nb").items()}
+    ckdir = tmp_path / "run" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    torch.save({"config": ck.EasyDict({"name": "infilling", "model": {}}), "infilling_params": ck.EasyDict(cfg),
+                "abnativ_params": {}, "model": sd}, ckdir / "hudiffnb.pt")
+    vhh = [KNOWN["caplacizumab_VHH"][0], KNOWN["trastuzumab_VH"][0]]
+    csv = tmp_path / "nanobert.csv"
+    with open(csv, "w") as f:
+        f.write(",vhhseq\n" + "".join(f"{i},{s}\n" for i, s in enumerate(vhh)))
+    out = cli.main(["--ckpt", str(ckdir / "hudiffnb.pt"), "--data_fpath", str(csv), "--numbering", "builtin",
+                    "--try_number", "3", "--seed", "3"])
+    lines = open(out).read().splitlines()
+    assert lines[0] == "Specific,name,hseq," and len(lines) == 1 + 2 * len(vhh)
+    for i, s in enumerate(vhh):
+        assert lines[1 + 2 * i] == f"nano,{i},{s}"
+        got = lines[2 + 2 * i].split(",")
+        assert got[:2] == ["humanization", f"{i}human_sample"]
+        key = "caplacizumab_VHH" if i == 0 else "trastuzumab_VH"
+        pos = 0
+        for cdr in KNOWN[key][2:]:                                   # CDR-IMGT 1-3 are not sampled (HEAVY_CDR_INDEX)
+            pos = got[2].index(cdr, pos) + 1
+    log = open(os.path.join(os.path.dirname(out), "log.txt")).read()
+    assert log.count("Need to re sample again.") >= 2 * 2            # tries 3 -> two rejected sweeps, third written

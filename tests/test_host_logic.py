@@ -113,6 +113,53 @@ def test_sample_jobs_batches_rows_with_global_ids():
     assert two.shape == (5, 2, 2, 291)
 
 
+def _reference_retry(rows_per_sweep, want, tries, accept):
+    """Literal walk of nanobody_scripts/nanosample.py:316-353 for one input over pre-drawn sweeps."""
+    written, sweep = [], 0
+    while want > 0 and tries > 0:
+        for row in rows_per_sweep[sweep]:
+            if want == 0:
+                break
+            if accept(row):
+                written.append(row)
+                want -= 1
+            elif tries == 1:
+                written.append(row)
+            tries -= 1
+        sweep += 1
+    return written, sweep
+
+
+def test_retry_loop_matches_reference_walk(monkeypatch):
+    """sample_jobs_with_retry == the reference's accept / re-sweep loop, for several (want, tries, replicas):
+    record every sweep the batched driver runs, then walk each input's own sweeps as the reference does."""
+    from hudiff_amd import sampler
+    jobs = _jobs(5)
+    probe = int(jobs[0].loc[0])
+    accept = lambda row: int(row[probe]) % 3 == 0                   # varies with global row id and sweep seed
+    real = sampler.sample_jobs
+    for want, tries, replicas in ((1, 10, 1), (2, 3, 2), (3, 4, 2), (1, 1, 3), (2, 5, 3), (0, 5, 2), (2, 0, 1)):
+        sweeps = {j.name: [] for j in jobs}
+
+        def recording(model, sub, *a, **kw):
+            res = real(model, sub, *a, **kw)
+            for i, j in enumerate(sub):
+                sweeps[j.name].append(res[i, 0])
+            return res
+        monkeypatch.setattr(sampler, "sample_jobs", recording)
+        got = sampler.sample_jobs_with_retry(FakeModel(), jobs, replicas, 7, want=want, tries=tries, accept=accept,
+                                             device_batch=3)
+        monkeypatch.setattr(sampler, "sample_jobs", real)
+        n_accept = 0
+        for i, j in enumerate(jobs):
+            want_rows, used = _reference_retry(sweeps[j.name] + [None], want, tries, accept)
+            assert used == len(sweeps[j.name]), (want, tries, replicas, j.name)      # no sweep too many or too few
+            assert len(got[i]) == len(want_rows) and all(np.array_equal(x, y) for x, y in zip(got[i], want_rows))
+            n_accept += sum(accept(r) for r in got[i])
+        if want and tries:
+            assert n_accept > 0 and any(len(v) > 1 for v in sweeps.values()) or tries == 1
+
+
 def test_checkpoint_envelopes(tmp_path):
     torch = pytest.importorskip("torch")
     from hudiff_amd import checkpoint as ck
