@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhudiff_hip.so")
+LIB_PATH = os.environ.get("HUDIFF_LIB") or os.path.join(HERE, "libhudiff_hip.so")    # HUDIFF_LIB: A/B builds
 
 HD_ABI_VERSION = 1
 HD_KIND_ANTIBODY, HD_KIND_NANOBODY = 0, 1

@@ -583,7 +583,13 @@ static int gemm_bk() {
     return bk;
 }
 
-template <int BM, int BN, int WM, int WN, int BKT>
+// HUDIFF_GEMM_NBUF=2: two LDS buffers, one barrier per k tile (tuning aid)
+static int gemm_nbuf() {
+    static int nb = [] { const char* e = getenv("HUDIFF_GEMM_NBUF"); return (e && atoi(e) == 2) ? 2 : 1; }();
+    return nb;
+}
+
+template <int BM, int BN, int WM, int WN, int BKT, int NB = 1>
 static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     Segs run = p.sg;
     if (!per_seg) {           // weights shared by all rows: treat the whole batch as one segment
@@ -599,7 +605,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     q.tiles_n = (q.N + BN - 1) / BN;
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
     const int pro = (q.stats || q.spart) ? 1 + q.pro_act : 0;      // 0 none, 1 LN, 2 LN+ReLU, 3 LN+GELU
-#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, 1, BKT>), grid, blk, 0, st, q)
+#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, NB, BKT>), grid, blk, 0, st, q)
     if (!conv) {
         switch (pro) {
             case 0: HD_LAUNCH(false, 0); break;
@@ -633,11 +639,17 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     if (stats_out != STATS_NONE || apply) p.part = ws.PART[ws.part_next];
     static const int small_tiles = [] { const char* e = getenv("HUDIFF_GEMM_SMALL"); return e ? atoi(e) : 1536; }();
     const long tiles128 = ((rows + 127) / 128) * ((p.N + 127) / 128);
-    if (big && tiles128 < small_tiles) {
+    // the BK = 16 kernels assume whole k tiles and 32-bit byte offsets inside every operand (gemm_k, FAST)
+    const long lda = p.lda, ldw = p.ldw ? p.ldw : p.N;
+    const bool fast_ok = p.Kc % 16 == 0 && rows * lda * 4 < (1L << 31) && (long)p.taps * p.Kc * ldw * 4 < (1L << 31);
+    p.a_bytes = fast_ok ? (uint32_t)(rows * lda * 4) : 0;
+    p.w_bytes = fast_ok ? (uint32_t)((long)p.taps * p.Kc * ldw * 4) : 0;
+    if (big && fast_ok && tiles128 < small_tiles) {
         // few 128-row tiles (narrow outputs of the token encoder): 64-row tiles balance the 256 CUs better
         launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else if (big) {
-        if (gemm_bk() == 32) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
+        if (gemm_bk() == 32 || !fast_ok) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
+        else if (gemm_nbuf() == 2) launch_gemm_t<128, 128, 2, 2, 16, 2>(p, conv, per_seg, st);
         else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);

@@ -23,8 +23,9 @@ static float run(GemmP q, int iters) {
     return ms / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int M = 74496;
+    const bool pc = argc > 1;      // any argument: only the production QKV kernel, for PC sampling / thread trace
     struct Shape { const char* name; int K, N, taps; } shapes[] = {
         {"qkv   K=768  N=1536", 768, 1536, 1}, {"oproj K=512  N=768", 512, 768, 1}, {"ff2   K=256  N=768", 256, 768, 1},
         {"g1    K=768  N=384", 768, 384, 1}, {"conv  K=7x384 N=384", 384, 384, 7}};
@@ -38,10 +39,18 @@ int main() {
     hipMemset(g, 0, 4096 * 4); hipMemset(st, 0, (size_t)M * 8);
     for (auto& s : shapes) {
         GemmP p{};
+        if (pc && argv[1][0] == 'p' && (s.K != 768 || s.N != 1536)) continue;
         p.A = A; p.lda = s.K; p.W = W; p.bias = g; p.C = C; p.ldc = s.N; p.N = s.N; p.Kc = s.K; p.taps = s.taps; p.dil = 4;
-        p.stats = st; p.gamma = g; p.beta = g;
+        p.stats = st; p.gamma = g; p.beta = g; p.ldw = s.N;
+        p.a_bytes = (uint32_t)((size_t)M * s.K * 4); p.w_bytes = (uint32_t)((size_t)s.taps * s.K * s.N * 4);
         p.sg.nseg = 1; p.sg.B = M / 291; p.sg.L = 291; p.sg.len[0] = 291;
         const double gf = 2.0 * M * s.K * s.taps * s.N * 1e-9;
+        if (pc) {       // "pc": QKV only (profiling); anything else: the production BK = 16 kernels on every shape
+            float t0 = s.taps == 1 ? run<128, 128, 2, 2, false, 0, 0, 1, 16>(p, 30) : run<128, 128, 2, 2, true, 0, 0, 1, 16>(p, 30);
+            float t1 = s.taps == 1 ? run<128, 128, 2, 2, false, 1, 0, 1, 16>(p, 30) : 0.f;
+            printf("%-22s BK=16: %8.1f us %6.1f TF | LN prologue %6.1f TF\n", s.name, t0 * 1e3, gf / t0, t1 > 0 ? gf / t1 : 0.0);
+            continue;
+        }
         float t[4];
         if (s.taps == 1) {
             t[0] = run<128, 128, 2, 2, false, 0, 0>(p, 5); t[1] = run<128, 128, 2, 2, false, 0, 1>(p, 5);
