@@ -151,6 +151,19 @@ __device__ __forceinline__ float pro_f(float x, float mean, float rstd, float g,
     return v;
 }
 
+// Two elements at once on the packed-fp32 pipe (v_pk_add / v_pk_mul / v_pk_fma: half the vector-ALU time of the scalar
+// form, identical roundings: subtract, multiply, fused multiply-add).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int PRO>
+__device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g, f32x2 b) {
+    if (PRO == 0) return x;
+    const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
+    f32x2 v = __builtin_elementwise_fma((x - m2) * r2, g, b);
+    if (PRO == 2) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
+    if (PRO == 3) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); }
+    return v;
+}
+
 // Shared GEMM epilogue: each wave transposes its accumulators through its own slice of LDS so that every lane owns
 // 4 consecutive columns of one row, then applies bias / activation / residual / dropout / addend on float4s, writes
 // with 16-B stores and (optionally) leaves the LayerNorm slice partials of the rows it wrote.
@@ -390,6 +403,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     uint32_t t_boff[AIT], w_boff[BIT];
     __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, FAST ? (int)p.a_bytes : 0, 0x00020000);
     __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, FAST ? (int)p.w_bytes : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gamma), 0, (FAST && PRO) ? Kc * 4 : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(beta), 0, (FAST && PRO) ? Kc * 4 : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
         t_ptr[i] = p.A + a_row[i] * p.lda; t_ok[i] = a_ok[i];
@@ -402,8 +417,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
         const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
         if (FAST) {
             if (PRO) {
-                rg = *reinterpret_cast<const f32x4*>(gamma + kk0 + 4 * a_kq);
-                rb = *reinterpret_cast<const f32x4*>(beta + kk0 + 4 * a_kq);
+                rg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rs, 16 * a_kq, kk0 * 4, 0));
+                rb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, 16 * a_kq, kk0 * 4, 0));
             }
             if (CONV && kk0 == 0) {                    // wave-uniform: first k tile of a tap
                 const int shift = (tap - half) * p.dil;
@@ -471,12 +486,17 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
             if (A_FULL || tid + 256 * i < BM * KQ) {
                 const float2 st = CONV ? rst[i] : a_st[i];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = pro_f<PRO>(ra[i][c], st.x, st.y, rg[c], rb[c]);
-                    // FAST: invalid lanes already loaded zeros through the descriptor's range check.  Rows past the
-                    // segment end are never stored, so only conv padding behind a prologue (must stay zero AFTER
-                    // LayerNorm + activation) still needs the select
-                    Aw[4 * a_kq + c][a_r[i]] = (FAST && !(CONV && PRO != 0)) ? v : (rav[i] ? v : 0.f);
+                for (int c2 = 0; c2 < 4; c2 += 2) {
+                    const f32x2 x2 = {ra[i][c2], ra[i][c2 + 1]}, g2 = {rg[c2], rg[c2 + 1]}, b2 = {rb[c2], rb[c2 + 1]};
+                    const f32x2 v2 = pro_f2<PRO>(x2, st.x, st.y, g2, b2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = c2 + e;
+                        // FAST: invalid lanes already loaded zeros through the descriptor's range check.  Rows past the
+                        // segment end are never stored, so only conv padding behind a prologue (must stay zero AFTER
+                        // LayerNorm + activation) still needs the select
+                        Aw[4 * a_kq + c][a_r[i]] = (FAST && !(CONV && PRO != 0)) ? v2[e] : (rav[i] ? v2[e] : 0.f);
+                    }
                 }
             }
         }
@@ -843,8 +863,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
             const f32x4 v = qraw[s];
             const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
             const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
-            qf[s][0] = (v[0] * cs.x - v[1] * sn.x) * 0.125f; qf[s][1] = (v[0] * sn.x + v[1] * cs.x) * 0.125f;
-            qf[s][2] = (v[2] * cs.y - v[3] * sn.y) * 0.125f; qf[s][3] = (v[2] * sn.y + v[3] * cs.y) * 0.125f;
+            // 1/sqrt(64) and log2(e) in one factor: the scores live in the log2 domain, exp() below is one v_exp_f32
+            constexpr float QS = 0.125f * 1.44269504088896340736f;
+            qf[s][0] = (v[0] * cs.x - v[1] * sn.x) * QS; qf[s][1] = (v[0] * sn.x + v[1] * cs.x) * QS;
+            qf[s][2] = (v[2] * cs.y - v[3] * sn.y) * QS; qf[s][3] = (v[2] * sn.y + v[3] * cs.y) * QS;
         }
         if (qt + ATT_THREADS / 64 < nqt) load_q(qt + ATT_THREADS / 64);
         // S^T tiles, two key tiles per pass so that two independent accumulator chains are in flight
@@ -854,9 +876,11 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
             constexpr int dummy = 0; (void)dummy;
             const bool two = kt + 1 < NKT;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            int key0 = kt * 16 + qi, key1 = (kt + 1) * 16 + qi;          // A operand row index i = lane & 15
-            key0 = key0 < L ? key0 : L - 1;
-            key1 = key1 < L ? key1 : L - 1;
+            // A operand row index i = lane & 15.  Only the last key tile can run past L (NKT = ceil(L / 16)): every
+            // other tile's addresses are a loop-invariant base + a compile-time offset (no vector-ALU work)
+            int key0 = kt * 16 + qi, key1 = (kt + 1) * 16 + qi;
+            if (kt == NKT - 1) key0 = key0 < L ? key0 : L - 1;
+            if (kt + 1 == NKT - 1) key1 = key1 < L ? key1 : L - 1;
             const float* kp0 = Ks + key0 * ATT_KS + 4 * g;
             const float* kp1 = Ks + key1 * ATT_KS + 4 * g;
 #pragma unroll
@@ -880,7 +904,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
+                if (kt == NKT - 1 && kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
                 mx = fmaxf(mx, st[kt][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -889,7 +913,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float e = expf(st[kt][r] - mx); st[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { float e = __builtin_amdgcn_exp2f(st[kt][r] - mx); st[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -903,7 +927,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 16 + 4 * g + r;
-                key = key < L ? key : L - 1;            // P is exactly 0 there
+                if (kt == NKT - 1) key = key < L ? key : L - 1;            // P is exactly 0 there
                 const float* vp = Vs + key * ATT_VS + qi;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dst[4 * r + dt] = vp[16 * dt];
@@ -977,8 +1001,9 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
         if (lane < 32) {
             const float xr = Qc[(long)b * att + h * ATT_HD + 2 * k], xi = Qc[(long)b * att + h * ATT_HD + 2 * k + 1];
             const float c = rope_cos[slot * 32 + k], s = rope_sin[slot * 32 + k];
-            qs[w][2 * k] = (xr * c - xi * s) * 0.125f;
-            qs[w][2 * k + 1] = (xr * s + xi * c) * 0.125f;
+            constexpr float QS = 0.125f * 1.44269504088896340736f;       // log2 domain, as attn_k
+            qs[w][2 * k] = (xr * c - xi * s) * QS;
+            qs[w][2 * k + 1] = (xr * s + xi * c) * QS;
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1009,7 +1034,7 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int key = lane + 64 * i;
-        const float e = (key < L) ? expf(sc[i] - mx) : 0.f;
+        const float e = (key < L) ? __builtin_amdgcn_exp2f(sc[i] - mx) : 0.f;
         if (key < 320) ps[w][key] = e;
         sum += e;
     }
