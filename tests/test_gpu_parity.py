@@ -213,6 +213,35 @@ def test_production_config_forward_vs_oracle(hip, kind):
         m.close()
 
 
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_big_batch_kernels_vs_oracle_and_small_batch_kernels(hip, kind):
+    """Launches with >= 8192 activation rows take the 128x128 / 64x128 BK = 16 GEMM kernels (buffer-descriptor
+    addressing, range-check zero padding) and the MFMA attention over the whole batch; smaller ones the generic
+    32x128 kernel.  Same rows through both, logits compared with each other (dropout faithful) and with the
+    oracle (dropout off) at production width."""
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    sd = S.random_state_dict(kind, cfg, seed=21)
+    B = 32 if kind == "ab" else 56                      # 9312 / 8512 rows: just above the switch
+    batch = S.synthetic_batch(kind, B, seed=9)
+    tokens = batch["tokens"].copy()
+    tokens[5] = np.where(tokens[5] == 22, batch["truth"][5], tokens[5])
+    m = _mk(hip, kind, cfg, sd)
+    try:
+        big = m(tokens, batch["region"], batch["chain"], dropout="faithful", seed=5, row0=100, step=3)
+        step = 4
+        for lo in range(0, B, step):
+            ch = None if batch["chain"] is None else np.concatenate([batch["chain"][lo:lo + step], batch["chain"][B + lo:B + lo + step]])
+            small = m(tokens[lo:lo + step], batch["region"][lo:lo + step], ch, dropout="faithful", seed=5, row0=100 + lo, step=3)
+            err = np.abs(big[lo:lo + step] - small).max()
+            assert err < 0.2 * LOGIT_TOL, (lo, err)
+        got = m(tokens, batch["region"], batch["chain"], dropout="off")
+        want = ho.OracleNet(kind, dict(cfg, dropout=0.0), sd)(tokens, batch["region"], batch["chain"])
+        assert np.abs(got - want).max() < LOGIT_TOL
+    finally:
+        m.close()
+
+
 def test_full_size_antibody_batch_properties(hip):
     """BASELINE configs[1] size (HuDiff-Ab, 256 rows per GPU): size-independent properties at full width.
     (a) rows are independent: the first 32 rows of the 256-row batch equal a 32-row run with the same global ids,
