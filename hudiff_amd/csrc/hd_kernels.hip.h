@@ -175,7 +175,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
     constexpr int EPI_FLOATS = 4 * 32 * ES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is wave-uniform by construction; readfirstlane tells the compiler, so that everything derived
+    // from it (row bases, buffer descriptors) lives in SGPRs and is advanced on the scalar unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int khalf = lane >> 5;
     const int N = p.N;
@@ -193,8 +195,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
     const int col = n0 + wn * WTN + e_c4;
     const bool col_ok = col < N;
+    const int colc = col_ok ? col : 0;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    // Global accesses of the epilogue: descriptor whose base is the first row of the current 4-row group (moved with
+    // scalar adds) + a lane offset fixed for the whole block; a lane switched off by BUF_OFF reads 0 / stores nothing
+    // (offset beyond num_records), so there is no per-row 64-bit address arithmetic on the vector ALU.
+    constexpr uint32_t BUF_OFF = 0x80000000u;
+    constexpr int BUF_MAX = 0x7FFFFFFF;
+    const uint32_t c_vo = (uint32_t)((e_r * p.ldc + colc) * 4);
+    const uint32_t r_vo = (uint32_t)((e_r * p.ldr + colc) * 4);
+    const uint32_t x_vo = (uint32_t)((e_r * p.lde + colc) * 4);
+    const int wrow0 = m0 + wm * WTM;                  // first tile row of this wave within the segment (uniform)
+    const int nv = min(WTN, N - (n0 + wn * WTN));     // valid columns of this wave's slice (uniform)
+    const float inv_nv = 1.0f / (float)max(nv, 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // residual values of this pass are requested up front (each lane reads exactly the elements it will
@@ -204,9 +218,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         if (p.resid) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
-                const int lrow = m0 + wm * WTM + 32 * i + it * RPI + e_r;
-                const long grow = (lrow < seg_rows) ? (long)rbase + lrow : (long)rbase;
-                rres[it] = *reinterpret_cast<const f32x4*>(p.resid + grow * p.ldr + (col_ok ? col : 0));
+                const int g0 = wrow0 + 32 * i + it * RPI;                       // uniform
+                const bool ok = g0 + e_r < seg_rows && col_ok;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.resid) + (long)(rbase + g0) * p.ldr, 0, BUF_MAX, 0x00020000);
+                rres[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : BUF_OFF), 0, 0));
             }
         }
 #pragma unroll
@@ -219,10 +235,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int rr = it * RPI + e_r;
-            const int lrow = m0 + wm * WTM + 32 * i + rr;
+            const int g0 = wrow0 + 32 * i + it * RPI;                           // uniform
+            const int lrow = g0 + e_r;
+            const bool valid = lrow < seg_rows && col_ok;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
-            if (lrow < seg_rows && col_ok) {
-                const long grow = (long)rbase + lrow;
+            if (valid) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
                 if (p.resid) v += rres[it];
@@ -231,9 +248,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     const int slot = p.sg.off[seg] + (lrow - b * Lc);
                     if (p.drop_mode == DROP_GEN) {
                         const uint32_t rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
+                        // (slot * N + col + c) * GOLD = h0 + c * GOLD (mod 2^32): one quarter-rate multiply per float4
+                        const uint32_t h0 = rk + (uint32_t)(slot * N + col) * 0x9E3779B9U;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const uint32_t w = mix32(rk + (uint32_t)(slot * N + col + c) * 0x9E3779B9U);
+                            const uint32_t w = mix32(h0 + (uint32_t)c * 0x9E3779B9U);
                             v[c] = (w >= p.drop_thresh) ? v[c] * p.drop_scale : 0.f;
                         }
                     } else {
@@ -242,22 +261,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                         for (int c = 0; c < 4; ++c) v[c] = mk[c] ? v[c] * p.drop_scale : 0.f;
                     }
                 }
-                if (p.extra) {
-                    const f32x4 ev = *reinterpret_cast<const f32x4*>(p.extra + grow * p.lde + col);
-                    v += ev;
-                }
-                *reinterpret_cast<f32x4*>(p.C + grow * p.ldc + col) = v;
+            }
+            if (p.extra) {
+                const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.extra) + (long)(rbase + g0) * p.lde, 0, BUF_MAX, 0x00020000);
+                v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, (int)(valid ? x_vo : BUF_OFF), 0, 0));
+            }
+            {
+                const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
+                    p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
             }
             if (p.part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
                 // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
                 // deviations) of its slice with DPP row reductions and the consumer merges the slices exactly
                 // (Chan et al.), which spares a separate read pass over the activation.
-                const bool valid = lrow < seg_rows && col_ok;
-                const int nv = min(WTN, N - (n0 + wn * WTN));                 // valid columns of this slice (uniform)
                 float ps = valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
                 ps = group_sum<LPR>(ps);
-                const float pm = ps / (float)max(nv, 1);
+                const float pm = ps * inv_nv;
                 float pq = 0.f;
                 if (valid) {
 #pragma unroll
@@ -273,7 +296,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        const int nv = min(WTN, N - (n0 + wn * WTN));
         for (int r = lane; r < WTM; r += 64) {
             const int lrow = m0 + wm * WTM + r;
             if (lrow < seg_rows && nv > 0)
