@@ -126,6 +126,10 @@ struct GemmP {
     long spart_rows;                  // slice width; merged on the fly in the prologue (non-CONV only)
     const float* gamma; const float* beta;
     int pro_act;
+    // LayerNorm folded into the weights (no prologue at all): W already holds diag(gamma) W, ln_s[n] = sum_k gamma_k W_kn,
+    // bias holds beta W + b, and the epilogue forms  rstd_r * (acc - mean_r * ln_s[n]) + bias[n]  from the row statistics
+    // (`stats` or `spart`, as for a prologue).  Exact algebra of LN(x) W + b; used where no activation follows the norm.
+    const float* ln_s;
     // epilogue
     int epi_act;
     const float* resid; int ldr;      // added before dropout (may alias C)
@@ -170,7 +174,8 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // smem must hold 4 * 32 * (BN/WN + 4) + 4 * (BM/WM) * 2 floats and be free (all waves past their last LDS read).
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                              int seg, int seg_rows, int rbase, int Lc, int m0, int n0, int by) {
+                                              const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
+                                              int by) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
@@ -196,8 +201,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int col = n0 + wn * WTN + e_c4;
     const bool col_ok = col < N;
     const int colc = col_ok ? col : 0;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
     if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    if (p.ln_s && col_ok) sv = *reinterpret_cast<const f32x4*>(p.ln_s + col);
     // Global accesses of the epilogue: descriptor whose base is the first row of the current 4-row group (moved with
     // scalar adds) + a lane offset fixed for the whole block; a lane switched off by BUF_OFF reads 0 / stores nothing
     // (offset beyond num_records), so there is no per-row 64-bit address arithmetic on the vector ALU.
@@ -240,6 +246,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const bool valid = lrow < seg_rows && col_ok;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
+                if (p.ln_s) {       // folded LayerNorm: rstd * (x W' - mean * colsum(W')); beta W + b is in `bias`
+                    const float2 st = rowst[wm * WTM + 32 * i + rr];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = st.y * __builtin_fmaf(-st.x, sv[c], v[c]);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
                 if (p.resid) v += rres[it];
@@ -331,7 +342,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     constexpr int BUF_FLOATS = BK * LDA + BK * LDB;
     constexpr int LOOP_FLOATS = NBUF * BUF_FLOATS, EPI_FLOATS = 4 * 32 * ES;
     constexpr int PART_FLOATS = 4 * WTM * 2;          // per-wave (mean, M2) of its WTM rows, written out coalesced
-    constexpr int SM_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
+    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
+    constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;   // + (mean, rstd) of the block's rows for a folded LayerNorm (p.ln_s)
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
     static_assert((BN * KQ) % 256 == 0, "every thread stages W");
@@ -369,6 +381,21 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
 
+    // (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
+    auto row_stat = [&](long grow) -> float2 {
+        if (!p.spart) return p.stats[grow];
+        const int P = (Kc + p.spw - 1) / p.spw;
+        float mean = 0.f;
+        for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + grow].x * (float)min(p.spw, Kc - s * p.spw);
+        mean /= (float)Kc;
+        float m2 = 0.f;
+        for (int s = 0; s < P; ++s) {
+            const float2 pr = p.spart[(long)s * p.spart_rows + grow];
+            const float d = pr.x - mean;
+            m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
+        }
+        return make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+    };
     // per-thread staging coordinates (fixed over the K loop)
     const int a_kq = tid % KQ;                        // k quad within the k tile (same for every A row of a thread)
     int a_r[AIT], a_pos[AIT];
@@ -384,23 +411,15 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;  // clamped: always a readable row
         a_st[i] = make_float2(0.f, 0.f);
-        if (PRO && !CONV) {
-            if (p.spart) {          // merge the producing GEMM's (mean, M2) slice partials (Chan et al.)
-                const int P = (Kc + p.spw - 1) / p.spw;
-                float mean = 0.f;
-                for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + a_row[i]].x * (float)min(p.spw, Kc - s * p.spw);
-                mean /= (float)Kc;
-                float m2 = 0.f;
-                for (int s = 0; s < P; ++s) {
-                    const float2 pr = p.spart[(long)s * p.spart_rows + a_row[i]];
-                    const float d = pr.x - mean;
-                    m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
-                }
-                a_st[i] = make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
-            } else {
-                a_st[i] = p.stats[a_row[i]];
-            }
+        if (PRO && !CONV) a_st[i] = row_stat(a_row[i]);
+    }
+    if (PRO == 0 && p.ln_s) {       // folded LayerNorm: the epilogue needs (mean, rstd) of every row of the tile
+        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += 256) {
+            const int lrow = m0 + r;
+            rowst[r] = row_stat(lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
         }
+        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
     }
     constexpr int B_KSTEP = 256 / (BN / 4);
     const int b_kr = tid / (BN / 4), b_nq = tid % (BN / 4);
@@ -616,7 +635,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     }
     if (NBUF == 2) __syncthreads();
 
-    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, seg, seg_rows, rbase, Lc, m0, n0, by);
+    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
 // ------------------------------------------------------------------------------------------------
