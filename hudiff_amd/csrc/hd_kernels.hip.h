@@ -850,7 +850,8 @@ constexpr int ATT_MAX_KT = 19;   // ceil(291 / 16)
 
 constexpr int ATT_THREADS = 512;   // 8 waves, two per SIMD: one wave's softmax / LDS latency hides under the other's MFMAs
 
-template <int NKT>
+// ABL (scripts/attn_probe.hip only): 1 = no softmax arithmetic, 2 = no S MFMAs, 3 = no PV MFMAs, 4 = no K / V staging
+template <int NKT, int ABL = 0>
 __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
                                                           const float* __restrict__ rope_cos,
                                                           const float* __restrict__ rope_sin,
@@ -864,7 +865,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
 
     // ---- stage K (rotated) and V ------------------------------------------------------------
-    for (int idx = tid; idx < L * 16; idx += ATT_THREADS) {
+    // (20 % of the kernel's time, bandwidth-bound, and with one 150 KB-LDS block per CU nothing overlaps it; letting
+    // waves 4-7 stage V while waves 0-3 start on K Q^T was measured 14 % slower -- scripts/attn_probe.hip)
+    for (int idx = tid; idx < (ABL == 4 ? 0 : L * 16); idx += ATT_THREADS) {
         const int key = idx >> 4, c4 = (idx & 15) * 4;
         const long row = sg.row(b, key);
         f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + koff + c4);
@@ -931,6 +934,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
                 if (two) kf1 = *reinterpret_cast<const f32x4*>(kp1 + 16 * s);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    if (ABL == 2) { acc0[c] += kf0[c] * qf[s][c]; if (two) acc1[c] += kf1[c]; continue; }
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf0[c], qf[s][c], acc0, 0, 0, 0);
                     if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf1[c], qf[s][c], acc1, 0, 0, 0);
                 }
@@ -941,22 +945,26 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
         }
         // softmax over keys (rows of S^T); this lane owns keys 16 kt + 4 g + r
         float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt == NKT - 1 && kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
+        if (ABL != 1) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float e = __builtin_amdgcn_exp2f(st[kt][r] - mx); st[kt][r] = e; sum += e; }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+                for (int r = 0; r < 4; ++r) {
+                    if (kt == NKT - 1 && kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, st[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float e = __builtin_amdgcn_exp2f(st[kt][r] - mx); st[kt][r] = e; sum += e; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+        } else {
+            sum = 1.f;
+        }
         const float inv = 1.0f / sum;
         // O^T[d, q] = sum_key V[key, d] P[key, q]; the V fragments of key tile kt+1 are read while the MFMAs of
         // tile kt run (register double buffer, order pinned with sched_group_barrier)
@@ -982,8 +990,10 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (ABL == 3) { oacc[dt][r] += vf[c][4 * r + dt] * st[kt][r]; continue; }
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c][4 * r + dt], st[kt][r], oacc[dt], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
