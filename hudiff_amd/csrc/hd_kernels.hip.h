@@ -865,20 +865,38 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
 
     // ---- stage K (rotated) and V ------------------------------------------------------------
-    // (20 % of the kernel's time, bandwidth-bound, and with one 150 KB-LDS block per CU nothing overlaps it; letting
-    // waves 4-7 stage V while waves 0-3 start on K Q^T was measured 14 % slower -- scripts/attn_probe.hip)
-    for (int idx = tid; idx < (ABL == 4 ? 0 : L * 16); idx += ATT_THREADS) {
-        const int key = idx >> 4, c4 = (idx & 15) * 4;
-        const long row = sg.row(b, key);
-        f32x4 kv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + koff + c4);
-        f32x4 vv = *reinterpret_cast<const f32x4*>(QKV + row * ldq + voff + c4);
-        const float2 cs = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
-        const float2 sn = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
-        f32x4 kr;
-        kr[0] = kv[0] * cs.x - kv[1] * sn.x; kr[1] = kv[0] * sn.x + kv[1] * cs.x;
-        kr[2] = kv[2] * cs.y - kv[3] * sn.y; kr[3] = kv[2] * sn.y + kv[3] * cs.y;
-        *reinterpret_cast<f32x4*>(Ks + key * ATT_KS + c4) = kr;
-        *reinterpret_cast<f32x4*>(Vs + key * ATT_VS + c4) = vv;
+    // Every request of the thread's share (K, V, cos, sin: 4 x NST loads) is issued before the first one is consumed.
+    // (With a run-time trip count hipcc leaves a rolled loop whose every iteration waits for its own loads: ten exposed
+    // HBM latencies per block, 20 % of the kernel's time with one 150 KB-LDS block per CU and nothing to overlap it.)
+    {
+        constexpr int NST = (NKT * 16 * 16 + ATT_THREADS - 1) / ATT_THREADS;
+        f32x4 kb[NST], vb[NST];
+        float2 cb[NST], sb[NST];
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + ATT_THREADS * k;
+            const int key = min(idx >> 4, L - 1), c4 = (idx & 15) * 4;
+            const long row = sg.row(b, key);
+            if (ABL != 4) {
+                kb[k] = *reinterpret_cast<const f32x4*>(QKV + row * ldq + koff + c4);
+                vb[k] = *reinterpret_cast<const f32x4*>(QKV + row * ldq + voff + c4);
+            }
+            cb[k] = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
+            sb[k] = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + ATT_THREADS * k;
+            if (ABL != 4 && idx < L * 16) {
+                const int key = idx >> 4, c4 = (idx & 15) * 4;
+                const f32x4 kv = kb[k];
+                f32x4 kr;
+                kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
+                kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
+                *reinterpret_cast<f32x4*>(Ks + key * ATT_KS + c4) = kr;
+                *reinterpret_cast<f32x4*>(Vs + key * ATT_VS + c4) = vb[k];
+            }
+        }
     }
     __syncthreads();
 
