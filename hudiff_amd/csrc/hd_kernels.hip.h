@@ -72,8 +72,26 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Exact (erf) GELU, x Phi(x) = 0.5 x erfc(-x / sqrt 2), with erfc(z >= 0) = t exp(-z^2 + P(t)), t = 1 / (1 + z / 2)
+// (Numerical Recipes' erfcc: fractional error < 1.2e-7 everywhere).  Against a float64 GELU the float32 evaluation is
+// within 3.8e-7 absolute -- the same as 0.5 x (1 + erff(x / sqrt 2)), which in addition loses all relative accuracy
+// for x < -4 where 1 + erf cancels -- at about half the vector-ALU instructions of the libm erff path (one v_rcp_f32,
+// one v_exp_f32, ten FMAs, no branches); those instructions are matrix time.
 __device__ __forceinline__ float gelu_f(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.5f, z, 1.0f));
+    float p = 0.17087277f;
+    p = __builtin_fmaf(p, t, -0.82215223f);
+    p = __builtin_fmaf(p, t, 1.48851587f);
+    p = __builtin_fmaf(p, t, -1.13520398f);
+    p = __builtin_fmaf(p, t, 0.27886807f);
+    p = __builtin_fmaf(p, t, -0.18628806f);
+    p = __builtin_fmaf(p, t, 0.09678418f);
+    p = __builtin_fmaf(p, t, 0.37409196f);
+    p = __builtin_fmaf(p, t, 1.00002368f);
+    p = __builtin_fmaf(p, t, -1.26551223f);
+    const float e = t * __builtin_amdgcn_exp2f(__builtin_fmaf(-z, z, p) * 1.44269504088896340736f);   // erfc(|x| / sqrt 2)
+    return 0.5f * x * (x >= 0.0f ? 2.0f - e : e);
 }
 __device__ __forceinline__ float act_f(float x, int act) {
     if (act == ACT_RELU) return fmaxf(x, 0.0f);
