@@ -70,3 +70,40 @@ def write_fasta_wrapped(records, path, width=60):
             f.write(f">{rid} {desc}\n")
             for i in range(0, len(seq), width):
                 f.write(seq[i:i + width] + "\n")
+
+
+def read_fasta(path):
+    """-> [(description line without '>', sequence)], multi-line records joined (stand-in for Bio.SeqIO.parse)."""
+    records, desc, chunks = [], None, []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            if line.startswith(">"):
+                if desc is not None:
+                    records.append((desc, "".join(chunks)))
+                desc, chunks = line[1:], []
+            elif desc is not None:
+                chunks.append(line)
+    if desc is not None:
+        records.append((desc, "".join(chunks)))
+    return records
+
+
+def split_fasta_for_save(csv_path, human_seqs):
+    """One '{idx}_human.fasta' per humanized sample under sample_human_fa/ next to the CSV, plus the empty
+    sample_human_pdb/ the structure predictor fills.  Nanobody (nanosample.py:163-182): record '{idx}_human_H', wrapped;
+    antibody (sample.py:326-349, items are (VH, VL) pairs): '>{idx}_human_H VH' and '>{idx}_human_L VL', two-line records
+    as ``Chain.to_fasta`` writes them."""
+    base = os.path.dirname(csv_path)
+    fa_dir, pdb_dir = os.path.join(base, "sample_human_fa"), os.path.join(base, "sample_human_pdb")
+    os.makedirs(fa_dir, exist_ok=True)
+    os.makedirs(pdb_dir, exist_ok=True)
+    for idx, seq in enumerate(human_seqs):
+        path = os.path.join(fa_dir, f"{idx}_human.fasta")
+        if isinstance(seq, str):
+            write_fasta_wrapped([(f"{idx}_human_H", "<unknown description>", seq)], path)
+        else:
+            write_fasta_2line([(f"{idx}_human_H", "VH", seq[0]), (f"{idx}_human_L", "VL", seq[1])], path)
+    return fa_dir

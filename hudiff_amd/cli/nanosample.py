@@ -20,7 +20,7 @@ from .. import inputs as I
 from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
 from ..model import NanoAntiTFNet
 from ..sampler import Job, sample_jobs_with_retry, seed_all
-from .common import get_logger, get_new_log_dir, load_numbered, write_fasta_wrapped
+from .common import get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_wrapped
 
 
 def build_parser():
@@ -126,7 +126,7 @@ def main(argv=None):
     logger.info("Save fasta fpath: {}".format(fasta))
     write_fasta_wrapped([(f"VH{args.fa_version}_{i}", "<unknown description>", s) for i, s in enumerate(human)], fasta)
     if args.structure:
-        raise NotImplementedError("--structure is outside the hot path")
+        split_fasta_for_save(save_fpath, human)
     logger.info("Length did not equal list: {}".format([]))
     logger.info("Wrong idx: {}".format([]))
     return save_fpath

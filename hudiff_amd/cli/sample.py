@@ -8,7 +8,7 @@ row, 'mouse,{name},{h},{l}' followed by 'humanization,{name}human_sample,{h},{l}
 Differences, all forced by what is absent offline: IMGT numbering uses anarci/abnumber when
 importable and otherwise the built-in slotter (``--numbering``; ``--numbered_fpath`` accepts pre-numbered
 residues); ``--sample_method inpaint`` and
-``--traditional_method`` (abnumber CDR grafting) are not part of the hot path and raise; the similarity
+``--traditional_method`` (abnumber CDR grafting onto human germlines) raise; the similarity
 search scores identity over the aligned IMGT slots instead of an abnumber alignment; noise comes from the
 library's counter-based generator keyed by (seed, global row, step), not torch's global mt19937 stream.
 """
@@ -25,7 +25,7 @@ from .. import inputs as I
 from ..checkpoint import antibody_model_from_checkpoint, load_checkpoint
 from ..model import model_selected
 from ..sampler import Job, sample_jobs, seed_all
-from .common import get_logger, get_new_log_dir, load_numbered, write_fasta_2line
+from .common import get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_2line
 
 
 def build_parser():
@@ -180,7 +180,7 @@ def main(argv=None):
         records += [(name, "VH", g_h), (name, "VL", g_l)]
     write_fasta_2line(records, os.path.join(log_dir, "sample_identity.fa"))
     if args.structure:
-        raise NotImplementedError("--structure (per-sample fasta for structure prediction) is outside the hot path")
+        split_fasta_for_save(save_fpath, human_rows)
     return save_fpath
 
 

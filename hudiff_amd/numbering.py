@@ -322,6 +322,12 @@ def number_sequence_builtin(aa_seq: str, allowed: str = "HKL") -> Tuple[Dict[str
     return {str(pos) + ins.strip(): a for (pos, ins), a in numbering}, cls
 
 
+def domain_sequence(aa_seq: str, allowed: str = "HKL") -> str:
+    """The numbered residues only (leader / constant-region / tag flanks dropped): ``abnumber.Chain(seq).seq``."""
+    numbering, _ = number_imgt(aa_seq, allowed)
+    return "".join(a for _, a in numbering if a != "-")
+
+
 def is_variable_domain(aa_seq: str, allowed: str = "H") -> bool:
     """Stand-in for the nanobody sampler's validity check ``Chain(g_h, scheme='imgt')`` (nanosample.py:338-353):
     the sequence must number as a complete domain with both cysteines, the tryptophan and the J motif."""

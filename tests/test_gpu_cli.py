@@ -162,3 +162,64 @@ def test_nanobody_cli_from_raw_sequences(tmp_path):
             pos = got[2].index(cdr, pos) + 1
     log = open(os.path.join(os.path.dirname(out), "log.txt")).read()
     assert log.count("Need to re sample again.") >= 2 * 2            # tries 3 -> two rejected sweeps, third written
+
+
+def _pdb_fasta(path):
+    from test_numbering import KNOWN
+    vh, vl, vhh = KNOWN["adalimumab_VH"][0], KNOWN["adalimumab_VK"][0], KNOWN["caplacizumab_VHH"][0]
+    path.write_text(">7ZZZ_1|Chain A|Spike protein S1|virus\nTNLCPFGEVFNATRFASVYAWN\n"
+                    f">7ZZZ_2|Chain B[auth H]|mAb heavy chain|Mus musculus\n{vh}ASTKGPSVFPLAP\n"
+                    f">7ZZZ_3|Chain C[auth L]|mAb light chain|Mus musculus\n{vl}RTVAAPSVFIFPPS\n"
+                    f">7ZZZ_4|Chain D|Nanobody X|Vicugna pacos\n{vhh}HHHHHH\n")
+    return vh, vl, vhh
+
+
+def test_single_antibody_cli(tmp_path):
+    """sample_for_anti_cdr: PDB-style FASTA -> domain cut -> sample_number rows (duplicates dropped but counted)."""
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd.cli import sample_for_anti_cdr as cli
+    cfg = dict(load_cfg("ab"), dropout=0.2)
+    sd = {k: torch.from_numpy(v) for k, v in load_weights("ab").items()}
+    ckpt = tmp_path / "hudiffab.pt"
+    torch.save({"fineconfig": ck.EasyDict({}), "pretrain_config": ck.EasyDict({"name": "trans_oadm", "model": cfg}), "model": sd}, ckpt)
+    fa = tmp_path / "7zzz.fasta"
+    vh, vl, _ = _pdb_fasta(fa)
+    out = cli.main(["--ckpt", str(ckpt), "--anti_complex_fasta", str(fa), "--log_dirpath", str(tmp_path / "logs"),
+                    "--batch_size", "3", "--sample_number", "7", "--numbering", "builtin"])
+    assert re.match(r"7zzz_shuffle_pair_\d{4}_", os.path.basename(os.path.dirname(out)))
+    lines = open(out).read().splitlines()
+    assert lines[0] == "Specific,name,hseq,lseq," and lines[1] == f"mouse,7zzz,{vh},{vl}"
+    human = [ln.split(",") for ln in lines[2:]]
+    assert 1 <= len(human) <= 7 and all(h[:2] == ["humanization", "7zzzhuman_sample"] for h in human)
+    assert len({(h[2], h[3]) for h in human}) == len(human)                 # no duplicates written
+    assert open(os.path.join(os.path.dirname(out), "log.txt")).read().count("Already Sample number") == 7
+    same = cli.main(["--ckpt", str(ckpt), "--heavy_seq", vh, "--light_seq", vl, "--log_dirpath", str(tmp_path / "logs2"),
+                     "--batch_size", "3", "--sample_number", "7", "--numbering", "builtin"])
+    assert [ln.split(",")[2:] for ln in open(same).read().splitlines()[2:]] == [h[2:] for h in human]   # same seed, same draw
+    assert "Unkown_shuffle_pair" in os.path.basename(os.path.dirname(same))
+
+
+def test_single_nanobody_cli(tmp_path):
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd.cli import sample_for_nano_cdr as cli
+    cfg = dict(load_cfg("nb"), dropout=0.5)
+    sd = {"infilling_pretrain." + k: torch.from_numpy(v) for k, v in load_weights("nb").items()}
+    ckpt = tmp_path / "hudiffnb.pt"
+    torch.save({"config": ck.EasyDict({"name": "infilling", "model": {}}), "infilling_params": ck.EasyDict(cfg),
+                "abnativ_params": {}, "model": sd}, ckpt)
+    fa = tmp_path / "7zzz.fasta"
+    _, _, vhh = _pdb_fasta(fa)
+    out = cli.main(["--ckpt", str(ckpt), "--nano_complex_fasta", str(fa), "--batch_size", "2", "--sample_number", "5",
+                    "--numbering", "builtin", "--structure", "True"])
+    log_dir = os.path.dirname(out)
+    assert os.path.dirname(log_dir) == str(tmp_path) and re.match(r"7zzz_finetune_vh_vhh_\d{4}_", os.path.basename(log_dir))
+    lines = open(out).read().splitlines()
+    assert lines[0] == "Specific,name,hseq," and lines[1] == f"Nano,7zzz,{vhh}HHHHHH"
+    human = [ln.split(",") for ln in lines[2:]]
+    assert all(h[:2] == ["humanization", "7zzz"] for h in human) and len(human) <= 5
+    log = open(os.path.join(log_dir, "log.txt")).read()
+    # random weights: samples do not number as heavy domains and are dropped (the reference would raise here)
+    assert log.count("Already Sample number") + log.count("dropped") >= 1
+    assert os.path.exists(os.path.join(log_dir, "sample_identity.fa")) and os.path.isdir(os.path.join(log_dir, "sample_human_pdb"))

@@ -205,3 +205,34 @@ def test_fasta_writers(tmp_path):
     assert p.read_text() == ">v007human0 VH\nEVQ\n>v007human0 VL\nDIQ\n"
     write_fasta_wrapped([("VHv_nano_0", "<unknown description>", "A" * 70)], p)
     assert p.read_text() == ">VHv_nano_0 <unknown description>\n" + "A" * 60 + "\n" + "A" * 10 + "\n"
+
+
+def test_fasta_reader_and_single_molecule_helpers(tmp_path):
+    """PDB-style FASTA -> chains (sample_for_anti_cdr.py:53-70, sample_for_nano_cdr.py:30-44); flanks are dropped by the
+    domain cut (``Chain(seq).seq``); per-sample FASTA files of --structure."""
+    from hudiff_amd.cli import common, sample_for_anti_cdr as ab, sample_for_nano_cdr as nb
+    from hudiff_amd import numbering as N
+    from test_numbering import KNOWN
+    vh, vl, vhh = KNOWN["trastuzumab_VH"][0], KNOWN["trastuzumab_VK"][0], KNOWN["caplacizumab_VHH"][0]
+    fa = tmp_path / "1abc.fasta"
+    fa.write_text(">1ABC_1|Chain A|Spike protein S1|virus\nTNLCPFGEVFNATRF\nASVYAWN\n"
+                  f">1ABC_2|Chain B[auth H]|2B04 heavy chain|Mus musculus (10090)\n{vh[:60]}\n{vh[60:]}ASTKGPSVFPLAP\n"
+                  f">1ABC_3|Chain C[auth L]|2B04 light chain|Mus musculus (10090)\n{vl}RTVAAPSVFIFPPS\n"
+                  f">1ABC_4|Chain D|Nanobody 3-2A2-4|Vicugna pacos (30538)\n{vhh}HHHHHH\n")
+    recs = common.read_fasta(str(fa))
+    assert len(recs) == 4 and recs[0][1] == "TNLCPFGEVFNATRFASVYAWN" and recs[1][0].startswith("1ABC_2|Chain B")
+    h, l = ab.get_h_l_seq_from_fasta(str(fa))
+    assert h == vh + "ASTKGPSVFPLAP" and l == vl + "RTVAAPSVFIFPPS"
+    assert N.domain_sequence(h) == vh and N.domain_sequence(l) == vl            # constant-region starts are cut off
+    nano = nb.get_nano_seq_from_fasta(str(fa))
+    assert nano == vhh + "HHHHHH" and N.domain_sequence(nano) == vhh
+    a, n = ab.build_parser().parse_args([]), nb.build_parser().parse_args([])
+    assert (a.batch_size, a.sample_number, a.seed, a.log_dirpath, a.anti_complex_fasta) == (10, 10, 42, "antibody_sample_log/", "fasta_file/7k9i.fasta")
+    assert (n.batch_size, n.sample_number, n.seed, n.inpaint_sample, n.model, n.fa_version) == (10, 100, 42, True, "finetune_vh", "v_nano")
+    csv = tmp_path / "log" / "sample_humanization_result.csv"
+    csv.parent.mkdir()
+    csv.write_text("Specific,name,hseq,\n")
+    d = common.split_fasta_for_save(str(csv), [vhh, (vh, vl)])
+    assert open(os.path.join(d, "0_human.fasta")).read().splitlines()[0] == ">0_human_H <unknown description>"
+    assert open(os.path.join(d, "1_human.fasta")).read().splitlines() == [">1_human_H VH", vh, ">1_human_L VL", vl]
+    assert os.path.isdir(tmp_path / "log" / "sample_human_pdb")
