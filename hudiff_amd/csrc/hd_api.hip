@@ -543,7 +543,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, cur(m).stream, m->sidew, se, d, m->side_vec);
         HIP_TRY(hipGetLastError());
     }
-    const size_t smem = (size_t)L * (ATT_KS + ATT_VS) * sizeof(float);
+    const size_t smem = (size_t)L * (ATT_KS + att_vs(L > 160 ? 19 : 10)) * sizeof(float);
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
@@ -761,7 +761,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
     if (ln) { p.ln_s = w.sqkv; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
     launch_gemm(m, p, false, false);
-    const size_t smem = (size_t)m->L * (ATT_KS + ATT_VS) * sizeof(float);
+    const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
     if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg);

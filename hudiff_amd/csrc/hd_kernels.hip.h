@@ -864,17 +864,21 @@ __global__ void __launch_bounds__(256) static_feature_k(const float* __restrict_
 constexpr int ATT_HD = 64;
 constexpr int ATT_KS = 68;   // K row stride in LDS (floats): 16-B aligned, spreads ds_read_b128 banks
 constexpr int ATT_VS = 68;   // V row stride: rows 4 apart land 16 banks apart, so the 4 key rows a ds_read_b32 touches do not collide
+// Short sequences (L <= 160, the nanobody model): with a 65-float V stride K + V take 80.9 KB, so TWO blocks share a CU's
+// 160 KB (and the kernel is held to 128 VGPRs): one block's staging and softmax run under the other's MFMAs.
+__host__ __device__ constexpr int att_vs(int nkt) { return nkt <= 10 ? 65 : ATT_VS; }
 constexpr int ATT_MAX_KT = 19;   // ceil(291 / 16)
 
 constexpr int ATT_THREADS = 512;   // 8 waves, two per SIMD: one wave's softmax / LDS latency hides under the other's MFMAs
 
 // ABL (scripts/attn_probe.hip only): 1 = no softmax arithmetic, 2 = no S MFMAs, 3 = no PV MFMAs, 4 = no K / V staging
 template <int NKT, int ABL = 0>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
+__global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
                                                           const float* __restrict__ rope_cos,
                                                           const float* __restrict__ rope_sin,
                                                           float* __restrict__ O, int ldo, int nhead, Segs sg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VS = att_vs(NKT);
     const int L = sg.L;
     float* Ks = smem;
     float* Vs = smem + (size_t)L * ATT_KS;
@@ -912,7 +916,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
                 kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
                 kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
                 *reinterpret_cast<f32x4*>(Ks + key * ATT_KS + c4) = kr;
-                *reinterpret_cast<f32x4*>(Vs + key * ATT_VS + c4) = vb[k];
+                if (VS % 4 == 0) {
+                    *reinterpret_cast<f32x4*>(Vs + key * VS + c4) = vb[k];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Vs[key * VS + c4 + c] = vb[k][c];
+                }
             }
         }
     }
@@ -1013,7 +1022,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_k(const float* __restrict
             for (int r = 0; r < 4; ++r) {
                 int key = kt * 16 + 4 * g + r;
                 if (kt == NKT - 1) key = key < L ? key : L - 1;            // P is exactly 0 there
-                const float* vp = Vs + key * ATT_VS + qi;
+                const float* vp = Vs + key * VS + qi;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dst[4 * r + dt] = vp[16 * dt];
             }
