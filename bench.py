@@ -46,36 +46,66 @@ def parse():
     ap.add_argument("--max-t", type=int, default=0, help="truncate every row to this many denoiser steps "
                     "(profiling aid; the JSON line is then marked truncated and is NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-rows", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-impl", choices=["auto", "torch", "numpy"], default="auto",
+                    help="CPU baseline on the oracle's PyTorch-CPU variant (auto: when torch is importable) or on numpy")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="2 = the batch runs as two concurrent half-batches on two streams (library default)")
     return ap.parse_args()
 
 
-def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T):
-    """The oracle (numpy port of the reference algorithm) on the host cores, bounded sample."""
+def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto"):
+    """The oracle (CPU port of the reference algorithm) on the host cores, bounded sample.  SURVEY.md §8d: the build's
+    CPU restatement, on PyTorch-CPU kernels where torch is present (oracle/hudiff_oracle_torch.py), else on numpy."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hudiff_oracle as ho
     from hudiff_amd import synthetic as S
     batch = S.synthetic_batch(kind, rows, seed=2023, mode=mode)
-    net = ho.OracleNet(kind, cfg, sd)
+    net, name, threads = None, "numpy+OpenBLAS", None
+    if impl in ("auto", "torch"):
+        try:
+            import torch
+            import hudiff_oracle_torch as hot
+            net, name, threads = hot.TorchOracleNet(kind, cfg, sd), "PyTorch-CPU kernels", torch.get_num_threads()
+        except ImportError:
+            if impl == "torch":
+                raise
+    if net is None:
+        net = ho.OracleNet(kind, cfg, sd)
     T = np.minimum(batch["T"], steps + 1)
     ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, 1),
-              seed=1, dropout_mode="philox")                                   # warm-up (BLAS threads, caches)
+              seed=1, dropout_mode="philox")                                   # warm-up (threads, caches)
+    if threads is not None:
+        # many-core hosts oversubscribe these matrix sizes (256 logical CPUs: 0.035 sequences/s on 128 threads, 0.145 on 16,
+        # scripts/cpu_threads_probe.py): one step per candidate thread count, the timed sample runs on the fastest
+        import torch
+        best = None
+        for n in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, 1),
+                      seed=1, dropout_mode="philox")
+            dtn = time.perf_counter() - t0
+            if best is None or dtn < best[0]:
+                best = (dtn, n)
+        threads = best[1]
+        torch.set_num_threads(threads)
+        name += f" (best of 8/16/32/64 threads on {os.cpu_count()} logical CPUs)"
     t0 = time.perf_counter()
     ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, steps),
               seed=1, dropout_mode="philox")
     dt = time.perf_counter() - t0
     per_step = dt / steps
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    if threads is None:
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count() or 1
     return {"value": rows / (per_step * mean_T), "unit": "sequences/s", "cores": int(threads), "kind": "port",
-            "sample": f"oracle/hudiff_oracle.py (numpy+OpenBLAS), {rows} rows x {steps} denoiser steps with philox "
+            "sample": f"oracle restatement of the reference loop on {name}, {rows} rows x {steps} denoiser steps with philox "
                       f"dropout in {dt:.1f} s, extrapolated to the mean T = {mean_T:.1f} steps per sequence"}
 
 
@@ -206,7 +236,8 @@ def main():
         if args.max_t > 0:
             out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
         if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(kind, cfg, sd, mode, args.cpu_rows, args.cpu_steps, float(batch["T"].mean()))
+            out["cpu_baseline"] = cpu_baseline(kind, cfg, sd, mode, args.cpu_rows, args.cpu_steps, float(batch["T"].mean()),
+                                               args.cpu_impl)
         print(json.dumps(out), flush=True)
     model.close()
     if dist is not None:
