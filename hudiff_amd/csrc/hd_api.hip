@@ -59,10 +59,10 @@ struct ByteNetW {   // one ByteNet block, both segments packed back to back
     const float *ln1_g, *ln1_b, *w1, *b1, *ln2_g, *ln2_b, *wc, *bc, *ln3_g, *ln3_b, *w3, *b3;
     int dil;
 };
-struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo, *sqkv; };   // sqkv: column sums of the LayerNorm-folded wqkv (a2 only)
+struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; };
 struct AttBlockW {
     AttLayerW a1, a2;
-    const float *n1_g, *n1_b, *n2_g, *n2_b, *wf1, *bf1, *wf2, *bf2, *sf1;   // sf1: column sums of the folded wf1
+    const float *n1_g, *n1_b, *n2_g, *n2_b, *wf1, *bf1, *wf2, *bf2;     // a2.wqkv / bqkv and wf1 / bf1 hold norm_hl1 / norm_hl2 folded in
 };
 
 struct Workspace {
@@ -362,25 +362,25 @@ static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::st
     return o;
 }
 
-// Folds y = LN(x; g, beta) W + b into the weights: W <- diag(g) W, s[n] = sum_k g_k W_kn, b <- beta W + b, so that
-// y = rstd (x W' - mean s) + b' needs no prologue (gemm_epilogue, p.ln_s).  Sums in double.
-static std::vector<float> fold_layernorm(std::vector<float>& w, std::vector<float>& b, const std::vector<float>& g,
-                                         const std::vector<float>& beta, int K, int N) {
+// Folds y = LN(x; g, beta) W + b into the weights: W <- diag(g) W with every column centred (its mean over k subtracted),
+// b <- beta W + b.  With centred columns x W equals (x - mean) W, so y = rstd (x W) + b needs neither a prologue nor a
+// mean-times-column-sum correction (gemm_epilogue, p.ln_fold).  Sums in double.
+static void fold_layernorm(std::vector<float>& w, std::vector<float>& b, const std::vector<float>& g,
+                           const std::vector<float>& beta, int K, int N) {
     std::vector<double> s(N, 0.0), t(N, 0.0);
     for (int k = 0; k < K; ++k)
         for (int n = 0; n < N; ++n) {
-            const float w0 = w[(size_t)k * N + n];
-            t[n] += (double)beta[k] * (double)w0;
-            const float wg = g[k] * w0;
-            w[(size_t)k * N + n] = wg;
-            s[n] += (double)wg;
+            const double w0 = w[(size_t)k * N + n];
+            t[n] += (double)beta[k] * w0;
+            s[n] += (double)g[k] * w0;
         }
-    std::vector<float> sf(N);
-    for (int n = 0; n < N; ++n) { sf[n] = (float)s[n]; b[n] = (float)((double)b[n] + t[n]); }
-    return sf;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n)
+            w[(size_t)k * N + n] = (float)((double)g[k] * (double)w[(size_t)k * N + n] - s[n] / K);
+    for (int n = 0; n < N; ++n) b[n] = (float)((double)b[n] + t[n]);
 }
 
-struct AttLayerOff { size_t wqkv, bqkv, wo, bo, sqkv; };
+struct AttLayerOff { size_t wqkv, bqkv, wo, bo; };
 static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, const std::string& p, int D, int A,
                                  const std::vector<float>* ln_g = nullptr, const std::vector<float>* ln_b = nullptr) {
     // fused [D, 3A] = [query | key | value]
@@ -394,8 +394,7 @@ static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, const std::string& p, i
     std::vector<float> b;
     append(b, ld.vec(p + "query.bias", A)); append(b, ld.vec(p + "key.bias", A)); append(b, ld.vec(p + "value.bias", A));
     AttLayerOff o;
-    o.sqkv = 0;
-    if (ln_g) o.sqkv = pk.add(fold_layernorm(w, b, *ln_g, *ln_b, D, 3 * A));
+    if (ln_g) fold_layernorm(w, b, *ln_g, *ln_b, D, 3 * A);
     o.wqkv = pk.add(w); o.bqkv = pk.add(b);
     o.wo = pk.add(ld.lin_t(p + "out_put.weight", D, A)); o.bo = pk.add(ld.vec(p + "out_put.bias", D));
     return o;
@@ -428,7 +427,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         for (auto& s : segn) pf.push_back(convp + s + "." + std::to_string(n) + ".");
         conv_off.push_back(pack_bytenet(ld, pk, pf, D, Dh, ks));
     }
-    struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2, sf1; };
+    struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2; };
     std::vector<AttOff> att_off;
     for (int n = 0; n < c.cs_layers; ++n) {
         std::string p = "self_at.layers." + std::to_string(n) + ".";
@@ -442,7 +441,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         o.n2_g = pk.add(n2g); o.n2_b = pk.add(n2b);
         {
             std::vector<float> wf1 = ld.lin_t(p + "ff_hl.0.weight", Fd, D), bf1 = ld.vec(p + "ff_hl.0.bias", Fd);
-            o.sf1 = pk.add(fold_layernorm(wf1, bf1, n2g, n2b, D, Fd));
+            fold_layernorm(wf1, bf1, n2g, n2b, D, Fd);
             o.wf1 = pk.add(wf1); o.bf1 = pk.add(bf1);
         }
         o.wf2 = pk.add(ld.lin_t(p + "ff_hl.2.weight", D, Fd)); o.bf2 = pk.add(ld.vec(p + "ff_hl.2.bias", D));
@@ -520,10 +519,10 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     for (int n = 0; n < c.dual_layers; ++n) m->conv.push_back(mk(conv_off[n], n));
     for (auto& o : att_off) {
         AttBlockW w;
-        w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo, nullptr};
-        w.a2 = {B0 + o.a2.wqkv, B0 + o.a2.bqkv, B0 + o.a2.wo, B0 + o.a2.bo, B0 + o.a2.sqkv};
+        w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo};
+        w.a2 = {B0 + o.a2.wqkv, B0 + o.a2.bqkv, B0 + o.a2.wo, B0 + o.a2.bo};
         w.n1_g = B0 + o.n1_g; w.n1_b = B0 + o.n1_b; w.n2_g = B0 + o.n2_g; w.n2_b = B0 + o.n2_b;
-        w.wf1 = B0 + o.wf1; w.bf1 = B0 + o.bf1; w.wf2 = B0 + o.wf2; w.bf2 = B0 + o.bf2; w.sf1 = B0 + o.sf1;
+        w.wf1 = B0 + o.wf1; w.bf1 = B0 + o.bf1; w.wf2 = B0 + o.wf2; w.bf2 = B0 + o.bf2;
         m->att.push_back(w);
     }
     m->regw = {B0 + r_emb, B0 + r_l0g, B0 + r_l0b, B0 + r_w, B0 + r_b, B0 + r_l1g, B0 + r_l1b, B0 + r_pe};
@@ -632,8 +631,8 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     q.tiles_m = q.tiles0 + (rows1 + BM - 1) / BM;
     q.tiles_n = (q.N + BN - 1) / BN;
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
-    // 0 none (also a LayerNorm folded into the weights, p.ln_s), 1 LN, 2 LN+ReLU, 3 LN+GELU
-    const int pro = (!q.ln_s && (q.stats || q.spart)) ? 1 + q.pro_act : 0;
+    // 0 none (also a LayerNorm folded into the weights, p.ln_fold), 1 LN, 2 LN+ReLU, 3 LN+GELU
+    const int pro = (!q.ln_fold && (q.stats || q.spart)) ? 1 + q.pro_act : 0;
 #define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, NB, BKT>), grid, blk, 0, st, q)
     if (!conv) {
         switch (pro) {
@@ -759,7 +758,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
-    if (ln) { p.ln_s = w.sqkv; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
+    if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
     launch_gemm(m, p, false, false);
     const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
@@ -804,7 +803,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     // K | V projections of LN1(at) for every row (columns [A, 3A) of the fused weight)
     GemmP p = base_gemm(m, sg);
     p.A = ws.AT; p.lda = D; p.W = w.a2.wqkv + A; p.ldw = 3 * A; p.bias = w.a2.bqkv + A; p.C = ws.QKV + A; p.ldc = 3 * A;
-    p.N = 2 * A; p.Kc = D; p.ln_s = w.a2.sqkv + A;
+    p.N = 2 * A; p.Kc = D; p.ln_fold = 1;
     use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
     launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
@@ -814,7 +813,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     // q = LN1(at_c) Wq + bq
     p = base_gemm(m, cs);
     p.A = ws.ATc; p.lda = D; p.W = w.a2.wqkv; p.ldw = 3 * A; p.bias = w.a2.bqkv; p.C = ws.Qc; p.ldc = A; p.N = A; p.Kc = D;
-    p.stats = ws.STc; p.ln_s = w.a2.sqkv;
+    p.stats = ws.STc; p.ln_fold = 1;
     launch_gemm(m, p, false, false);
     hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
                        m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -826,7 +825,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     hipLaunchKernelGGL(row_stats_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.ATc, D, D, B, ws.STc);
     p = base_gemm(m, cs);
     p.A = ws.ATc; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1c; p.ldc = Fd; p.N = Fd; p.Kc = D;
-    p.stats = ws.STc; p.ln_s = w.sf1; p.epi_act = ACT_RELU;
+    p.stats = ws.STc; p.ln_fold = 1; p.epi_act = ACT_RELU;
     launch_gemm(m, p, false, false);
     p = base_gemm(m, cs);
     p.A = ws.F1c; p.lda = Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Xc; p.ldc = D; p.N = D; p.Kc = Fd; p.resid = ws.Xc; p.ldr = D;
@@ -868,7 +867,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
-        p.ln_s = w.sf1; p.epi_act = ACT_RELU;      // LN2 folded into wf1 / bf1
+        p.ln_fold = 1; p.epi_act = ACT_RELU;       // LN2 folded into wf1 / bf1
         use_partials(m, p);         // statistics of `at`: partials left by the second attention's out-projection
         launch_gemm(m, p, false, false);
         p = base_gemm(m, sg);

@@ -144,10 +144,13 @@ struct GemmP {
     long spart_rows;                  // slice width; merged on the fly in the prologue (non-CONV only)
     const float* gamma; const float* beta;
     int pro_act;
-    // LayerNorm folded into the weights (no prologue at all): W already holds diag(gamma) W, ln_s[n] = sum_k gamma_k W_kn,
-    // bias holds beta W + b, and the epilogue forms  rstd_r * (acc - mean_r * ln_s[n]) + bias[n]  from the row statistics
-    // (`stats` or `spart`, as for a prologue).  Exact algebra of LN(x) W + b; used where no activation follows the norm.
-    const float* ln_s;
+    // LayerNorm folded into the weights (no prologue at all): W holds diag(gamma) W with every COLUMN CENTRED (its mean
+    // over k subtracted), bias holds beta W + b.  Since sum_k (x_k - mean) c = 0 for any constant c, centring the columns
+    // makes  x W  equal  (x - mean) W : the row mean drops out inside the dot product and the epilogue only forms
+    //   rstd_r * acc + bias[n]   from the row statistics (`stats` or `spart`, as for a prologue).
+    // Exact algebra of LN(x) W + b with the round-off behaviour of the direct form (no mean * column-sum term that could
+    // cancel); used where no activation follows the norm.
+    int ln_fold;
     // epilogue
     int epi_act;
     const float* resid; int ldr;      // added before dropout (may alias C)
@@ -219,9 +222,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int col = n0 + wn * WTN + e_c4;
     const bool col_ok = col < N;
     const int colc = col_ok ? col : 0;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
-    if (p.ln_s && col_ok) sv = *reinterpret_cast<const f32x4*>(p.ln_s + col);
     // Global accesses of the epilogue: descriptor whose base is the first row of the current 4-row group (moved with
     // scalar adds) + a lane offset fixed for the whole block; a lane switched off by BUF_OFF reads 0 / stores nothing
     // (offset beyond num_records), so there is no per-row 64-bit address arithmetic on the vector ALU.
@@ -264,11 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const bool valid = lrow < seg_rows && col_ok;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
-                if (p.ln_s) {       // folded LayerNorm: rstd * (x W' - mean * colsum(W')); beta W + b is in `bias`
-                    const float2 st = rowst[wm * WTM + 32 * i + rr];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = st.y * __builtin_fmaf(-st.x, sv[c], v[c]);
-                }
+                if (p.ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
                 if (p.resid) v += rres[it];
@@ -361,7 +359,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     constexpr int LOOP_FLOATS = NBUF * BUF_FLOATS, EPI_FLOATS = 4 * 32 * ES;
     constexpr int PART_FLOATS = 4 * WTM * 2;          // per-wave (mean, M2) of its WTM rows, written out coalesced
     constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
-    constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;   // + (mean, rstd) of the block's rows for a folded LayerNorm (p.ln_s)
+    constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;   // + (mean, rstd) of the block's rows for a folded LayerNorm (p.ln_fold)
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
     static_assert((BN * KQ) % 256 == 0, "every thread stages W");
@@ -431,7 +429,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
         a_st[i] = make_float2(0.f, 0.f);
         if (PRO && !CONV) a_st[i] = row_stat(a_row[i]);
     }
-    if (PRO == 0 && p.ln_s) {       // folded LayerNorm: the epilogue needs (mean, rstd) of every row of the tile
+    if (PRO == 0 && p.ln_fold) {    // folded LayerNorm: the epilogue needs rstd of every row of the tile
         float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
         for (int r = tid; r < BM; r += 256) {
             const int lrow = m0 + r;
