@@ -2,11 +2,14 @@
 //
 // Everything the denoiser forward needs is one of:
 //   gemm_k        fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM  C = epi( pro(A) @ W + bias )
-//                 pro : optional LayerNorm(+ReLU/GELU) of the A rows from precomputed (mean, rstd)
+//                 pro : optional LayerNorm + ReLU/GELU of the A rows from precomputed or merged (mean, rstd); a LayerNorm
+//                       with no activation behind it is folded into W instead (GemmP::ln_fold: no prologue)
 //                 CONV: the k=7 dilated ByteNet convolution as 7 row-shifted tap GEMMs, zero outside
 //                       the chain segment (model/encoder/model.py:170-180 via sequence_models MaskedConv1d)
-//                 epi : + bias, activation, + residual, functional dropout (generated or injected),
-//                       + post-dropout addend, strided store
+//                 epi : [rstd scale of a folded LayerNorm] + bias, activation, + residual, functional dropout
+//                       (generated or injected), + post-dropout addend, strided store, LayerNorm slice partials
+//                 The BK = 16 instantiations keep their K loop free of vector-ALU instructions (buffer loads with
+//                 SGPR descriptors, immediate-offset LDS reads): on gfx950 VALU and MFMA time-slice one issue port.
 //   attn_k        RoPE + softmax(QK^T/8) V for one (row, head): K/V staged in LDS, S^T = K Q^T kept in
 //                 MFMA accumulators (16x16x4 f32) so the softmax is lane-local and P feeds PV directly
 //                 (model/encoder/cross_attention.py:149-173)
