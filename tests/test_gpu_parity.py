@@ -274,6 +274,28 @@ def test_full_size_antibody_batch_properties(hip):
         m.close()
 
 
+def test_odd_batch_splits_into_uneven_lanes(hip):
+    """B = 129 at production width: the two lanes get 65 + 64 rows; the result must equal the two halves sampled on
+    their own with the matching global row ids (noise is keyed by the global row, not by the lane)."""
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG)
+    m = _mk(hip, "ab", cfg, S.random_state_dict("ab", cfg, seed=4))
+    try:
+        B = 129
+        batch = S.synthetic_batch("ab", B, seed=6)
+        T = np.minimum(batch["T"], 2)
+        T[100] = 1
+        out = m.sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=7, row0=40)
+        for lo, hi in ((0, 65), (65, 129)):
+            ch = np.concatenate([batch["chain"][lo:hi], batch["chain"][B + lo:B + hi]])
+            part = m.sample(batch["tokens"][lo:hi], batch["region"][lo:hi], ch, batch["order"][lo:hi], T[lo:hi], seed=7,
+                            row0=40 + lo, lanes=1)
+            assert np.array_equal(out[lo:hi], part), (lo, hi)
+        assert ((out != batch["tokens"]).sum(1) == T).all()
+    finally:
+        m.close()
+
+
 def test_large_batch_properties(hip):
     """BASELINE-size batch (B = 256, nanobody width): size-independent properties, no oracle.
     Rows are independent, so (a) duplicated rows with the same global id and noise give identical
