@@ -78,6 +78,7 @@ struct Workspace {
     float* LOGITS = nullptr;                                 // [B, L, n_tokens] (hd_forward)
     float *ATc = nullptr, *Xc = nullptr, *Qc = nullptr, *Oc = nullptr, *F1c = nullptr;   // pruned last block: [B, *]
     float2* STc = nullptr;
+    float *PW = nullptr, *YV = nullptr;                      // pruned last block: p_j rstd_j [B, nhead, 320], weighted input rows [B, nhead, D]
     int32_t *tokens = nullptr, *tokens0 = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
     int capT = 0;
     float* qnoise = nullptr; size_t qnoise_cap = 0;
@@ -166,7 +167,10 @@ extern "C" double hd_flops_per_row_sample_step(const HdConfig* c) {
     // block (2nd attention's query / core / out projection, feed-forward) and of the decoder that are evaluated
     // for the visited row only
     const double L = c->max_len, D = c->sum_d_model, A = c->att_model, Fd = c->dim_feedforward;
-    return hd_flops_per_row_forward(c) - (L - 1) * (4 * D * A + 4 * L * A + 4 * D * Fd + 2 * D * c->n_tokens);
+    // ... and the V projection of the last attention is replaced by a weighted sum of the input rows per head
+    // (2 nhead L D) and one D x A projection for the visited row
+    return hd_flops_per_row_forward(c) - (L - 1) * (4 * D * A + 4 * L * A + 4 * D * Fd + 2 * D * c->n_tokens)
+           - (L - 1) * 2 * D * A + 2.0 * c->nhead * L * D;
 }
 
 extern "C" HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
@@ -581,6 +585,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
+    HD_TRY(dalloc(ws, &ws.PW, (size_t)B * m->cfg.nhead * 320)); HD_TRY(dalloc(ws, &ws.YV, (size_t)B * m->cfg.nhead * m->D));
     HD_TRY(dalloc(ws, &ws.tokens, M)); HD_TRY(dalloc(ws, &ws.tokens0, M)); HD_TRY(dalloc(ws, &ws.region, M)); HD_TRY(dalloc(ws, &ws.chain, (size_t)2 * B));
     HD_TRY(dalloc(ws, &ws.T, (size_t)B));
     ws.capB = B;
@@ -800,11 +805,15 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     const int D = m->D, A = m->A, Fd = m->Fd, B = sg.B;
     Segs cs{};                      // compact [B, *] matrices: one "sequence" of B single-slot rows
     cs.nseg = 1; cs.B = B; cs.L = 1; cs.len[0] = 1;
-    // K | V projections of LN1(at) for every row (columns [A, 3A) of the fused weight)
+    // K projection of LN1(at) for every row (columns [A, 2A) of the fused weight).  V is never projected for all rows:
+    // the one query of each sequence takes its value side through the input rows (row_value_k / head_proj_k).
+    static const bool value_via_rows = [] { const char* e = getenv("HUDIFF_PRUNE_V"); return !(e && atoi(e) == 0); }();
+    const bool via_rows = value_via_rows && m->cfg.nhead <= RV_MAX_HEADS && m->L <= 320;
     GemmP p = base_gemm(m, sg);
     p.A = ws.AT; p.lda = D; p.W = w.a2.wqkv + A; p.ldw = 3 * A; p.bias = w.a2.bqkv + A; p.C = ws.QKV + A; p.ldc = 3 * A;
-    p.N = 2 * A; p.Kc = D; p.ln_fold = 1;
+    p.N = via_rows ? A : 2 * A; p.Kc = D; p.ln_fold = 1;
     use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
+    const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
     launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -816,7 +825,13 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.stats = ws.STc; p.ln_fold = 1;
     launch_gemm(m, p, false, false);
     hipLaunchKernelGGL(attn_row_k, dim3((B * m->cfg.nhead + 3) / 4), dim3(256), 0, st, ws.Qc, ws.QKV, 3 * A, A, m->rope_cos,
-                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
+                       m->rope_sin, ws.Oc, m->cfg.nhead, ws.order, ws.T, m->sTmax, cur(m).rs, sg, via_rows ? ws.PW : nullptr,
+                       at_part, at_pw, at_rows, D);
+    if (via_rows) {
+        hipLaunchKernelGGL(row_value_k, dim3(B, (D + 255) / 256), dim3(256), 0, st, ws.AT, D, ws.PW, ws.YV, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(head_proj_k, dim3((B + 3) / 4, m->cfg.nhead), dim3(256), (size_t)4 * D * sizeof(float), st, ws.YV, D,
+                           w.a2.wqkv + 2 * A, 3 * A, w.a2.bqkv + 2 * A, ws.Oc, A, m->cfg.nhead, B);
+    }
     // at_c = at_c + o Wo + bo
     p = base_gemm(m, cs);
     p.A = ws.Oc; p.lda = A; p.W = w.a2.wo; p.bias = w.a2.bo; p.C = ws.ATc; p.ldc = D; p.N = D; p.Kc = A; p.resid = ws.ATc; p.ldr = D;

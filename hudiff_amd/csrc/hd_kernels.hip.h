@@ -1080,12 +1080,16 @@ __global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ s
 
 // One wave per (sequence, head).  Qc: [B, att] compact query projection; QKV: full-row buffer holding K at column
 // `att + h*64` and V at `2*att + h*64`.  Oc: [B, att].
+// With Pw != nullptr the wave stops after the softmax and leaves  Pw[(b * nhead + h) * 320 + key] = p_key * rstd_key
+// (rstd of the key's input row, merged from the producer's LayerNorm slice partials `spart`): the value side is then
+// evaluated through the INPUT rows (row_value_k + head_proj_k below) and the V projection of all rows is never formed.
 __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, const float* __restrict__ QKV, int ldq,
                                                    int att, const float* __restrict__ rope_cos,
                                                    const float* __restrict__ rope_sin, float* __restrict__ Oc,
                                                    int nhead, const int32_t* __restrict__ order,
                                                    const int32_t* __restrict__ T, int Tmax,
-                                                   const RunState* __restrict__ rs, Segs sg) {
+                                                   const RunState* __restrict__ rs, Segs sg, float* __restrict__ Pw,
+                                                   const float2* __restrict__ spart, int spw, long spart_rows, int Kc) {
     __shared__ float qs[4][ATT_HD];
     __shared__ float ps[4][320];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1136,6 +1140,29 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
         sum += e;
     }
     sum = wave_sum(sum);
+    if (Pw) {
+        const float inv = 1.0f / sum;
+        const int P = (Kc + spw - 1) / spw;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int key = lane + 64 * i;
+            if (key < L) {
+                const long row = sg.row(b, key);
+                float mean = 0.f;               // Chan merge of the row's (mean, M2) slice partials -> rstd
+                for (int s2 = 0; s2 < P; ++s2) mean += spart[(long)s2 * spart_rows + row].x * (float)min(spw, Kc - s2 * spw);
+                mean /= (float)Kc;
+                float m2 = 0.f;
+                for (int s2 = 0; s2 < P; ++s2) {
+                    const float2 pr = spart[(long)s2 * spart_rows + row];
+                    const float d = pr.x - mean;
+                    m2 += pr.y + (float)min(spw, Kc - s2 * spw) * d * d;
+                }
+                const float e = __builtin_amdgcn_exp2f(sc[i] - mx);
+                Pw[(long)bh * 320 + key] = e * inv * (1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+            }
+        }
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     // O[d] = sum_key p[key] V[key, d]; lane = d
@@ -1143,6 +1170,75 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
     for (int key = 0; key < L; ++key)
         o += ps[w][key] * QKV[(long)sg.row(b, key) * ldq + 2 * att + h * ATT_HD + lane];
     Oc[(long)b * att + h * ATT_HD + lane] = o / sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Value side of the pruned last attention, through the input rows.  With the LayerNorm folded into column-centred
+// weights, v_j = rstd_j (W"v^T x_j) + t_v, hence for the one query of a sequence
+//   o = sum_j p_j v_j = W"v^T ( sum_j p_j rstd_j x_j ) + t_v          (sum_j p_j = 1):
+// a probability-weighted sum of the INPUT rows per head (row_value_k) followed by one D x 64 projection per head
+// (head_proj_k) replaces the V projection of all L rows (2 L D A flops per sequence) -- exact algebra, no RoPE on V.
+//   row_value_k : block = sequence.  Y[b, h, c] = sum_j Pw[b, h, j] X[row(b, j), c]        (Pw already holds p_j rstd_j)
+//   head_proj_k : block = sequence.  Oc[b, h*64 + d] = sum_c Y[b, h, c] Wv[c, h*64 + d] + tv[h*64 + d]
+// ------------------------------------------------------------------------------------------------
+constexpr int RV_MAX_HEADS = 8;
+// grid = (sequences, ceil(D / 256)): a thread owns one column for all heads; the row loop is unrolled so that eight row
+// loads are in flight per thread (the kernel is bound by reading X once: L D floats per sequence)
+__global__ void __launch_bounds__(256) row_value_k(const float* __restrict__ X, int D, const float* __restrict__ Pw,
+                                                    float* __restrict__ Y, int nhead, Segs sg) {
+    __shared__ float ps[320][RV_MAX_HEADS];
+    const int b = blockIdx.x, L = sg.L, tid = threadIdx.x;
+    for (int i = tid; i < RV_MAX_HEADS * 320; i += 256) {
+        const int key = i / RV_MAX_HEADS, h = i % RV_MAX_HEADS;
+        ps[key][h] = (key < L && h < nhead) ? Pw[((long)b * nhead + h) * 320 + key] : 0.f;
+    }
+    __syncthreads();
+    const int c = blockIdx.y * 256 + tid;
+    if (c >= D) return;
+    float acc[RV_MAX_HEADS];
+#pragma unroll
+    for (int h = 0; h < RV_MAX_HEADS; ++h) acc[h] = 0.f;
+    // rows of a sequence are contiguous within a chain segment: walk each segment with a constant stride
+    for (int s2 = 0; s2 < sg.nseg; ++s2) {
+        const float* xr = X + ((long)sg.base[s2] + (long)b * sg.len[s2]) * D + c;
+        const int j0 = sg.off[s2], n = sg.len[s2];
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) {
+            const float xv = xr[(long)j * D];
+#pragma unroll
+            for (int h = 0; h < RV_MAX_HEADS; ++h) acc[h] = __builtin_fmaf(ps[j0 + j][h], xv, acc[h]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < RV_MAX_HEADS; ++h)
+        if (h < nhead) Y[((long)b * nhead + h) * D + c] = acc[h];
+}
+
+// grid = (ceil(B / 4), nhead): a block projects one head of four sequences, so that the head's D x 64 weight slice is read
+// once per four sequences; thread = (sequence of the group, output feature d)
+__global__ void __launch_bounds__(256) head_proj_k(const float* __restrict__ Y, int D, const float* __restrict__ Wv, int ldw,
+                                                    const float* __restrict__ tv, float* __restrict__ Oc, int att, int nhead,
+                                                    int B) {
+    extern __shared__ __attribute__((aligned(16))) float ys[];        // [4, D]
+    const int h = blockIdx.y, b0 = blockIdx.x * 4, tid = threadIdx.x;
+    for (int i = tid; i < 4 * D; i += 256) {
+        const int bb = i / D, c = i % D;
+        ys[i] = b0 + bb < B ? Y[((long)(b0 + bb) * nhead + h) * D + c] : 0.f;
+    }
+    __syncthreads();
+    const int bb = tid >> 6, d = tid & 63;
+    const float* yh = ys + bb * D;
+    const float* wp = Wv + h * ATT_HD + d;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = 0;
+    for (; c + 3 < D; c += 4) {
+        a0 = __builtin_fmaf(yh[c], wp[(long)c * ldw], a0);
+        a1 = __builtin_fmaf(yh[c + 1], wp[(long)(c + 1) * ldw], a1);
+        a2 = __builtin_fmaf(yh[c + 2], wp[(long)(c + 2) * ldw], a2);
+        a3 = __builtin_fmaf(yh[c + 3], wp[(long)(c + 3) * ldw], a3);
+    }
+    for (; c < D; ++c) a0 = __builtin_fmaf(yh[c], wp[(long)c * ldw], a0);
+    if (b0 + bb < B) Oc[(long)(b0 + bb) * att + h * ATT_HD + d] = ((a0 + a1) + (a2 + a3)) + tv[h * ATT_HD + d];
 }
 
 // ------------------------------------------------------------------------------------------------

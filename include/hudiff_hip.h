@@ -155,7 +155,8 @@ HdStatus hd_sync(HdModel* m);
 HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps);
 /* Algorithmic FLOPs of one forward of one row (SURVEY.md §8d formula). */
 double hd_flops_per_row_forward(const HdConfig* cfg);
-/* FLOPs one hd_sample step actually executes per row (last attention block pruned to the visited row). */
+/* FLOPs one hd_sample step actually executes per row (last attention block pruned to the visited row, its value side
+ * taken through the input rows instead of a V projection of every row). */
 double hd_flops_per_row_sample_step(const HdConfig* cfg);
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
