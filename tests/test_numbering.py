@@ -151,3 +151,23 @@ def test_rows_from_raw_sequences():
     assert ntok.shape == (T.H_LEN,) and 80 <= len(nloc) <= 93
     with pytest.raises(RuntimeError):
         I.number_sequence(h, "anarci") if I.numbering_backend() == "builtin" else (_ for _ in ()).throw(RuntimeError())
+
+
+def test_edge_cases():
+    """Lower case, an unknown residue, a CDR3 beyond the model's 37 slots (extra insertions are numbered but have no slot,
+    as with ANARCI output in the reference: sample.py:107-131), a lambda chain that occupies IMGT 81 / 82."""
+    vh = KNOWN["trastuzumab_VH"][0]
+    d, c = N.number_sequence_builtin(vh.lower())
+    assert c == "H" and d["23"] == "C" and d["104"] == "C"
+    d, _ = N.number_sequence_builtin(vh.replace("NIKD", "NXKD"))
+    assert [d[str(p)] for p in range(27, 39)] == list("GFNX----KDTY")
+    assert I._TK.seq2idx(I.slot_residues(d, "H"))[T.HEAVY_POSITIONS_dict["30"]] == 20          # X -> token 20
+    long = vh.replace("SRWGGDGFYAMDY", "SR" + "GY" * 19 + "MDY")                             # 43-residue CDR3
+    d, _ = N.number_sequence_builtin(long)
+    extra = [k for k in d if k not in T.HEAVY_POSITIONS_dict]
+    assert sorted(extra) == ["111M", "111N", "111O", "112M", "112N", "112O"]
+    assert sum(v != "-" for v in I.slot_residues(d, "H")) == len(long) - 6
+    vl6 = ("NFMLTQPHSVSESPGKTVTISCTRSSGSIASNYVQWYQQRPGSSPTTVIYEDNQRPSGVPDRFSGSIDSSSNSASLTISGLKTEDEADYYCQSYDSSNHVVFGGGTKLTVL")
+    d, c = N.number_sequence_builtin(vl6)
+    assert c == "L" and (d["80"], d["81"], d["82"], d["83"]) == ("I", "D", "S", "S")
+    assert "".join(d[str(p)] for p in range(105, 118)) == "QSYDS---SNHVV"
