@@ -58,11 +58,68 @@ def EasyDict(*a, **k):
     return sys.modules["easydict"].EasyDict(*a, **k)
 
 
-def load_checkpoint(path, map_location="cpu"):
-    """torch.load(path) tolerant of EasyDict configs (torch >= 2.6 defaults to weights_only=True)."""
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object"}
+_SAFE_EXACT = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("easydict", "EasyDict"),
+               ("numpy", "dtype"), ("numpy", "ndarray"), ("_codecs", "encode"), ("argparse", "Namespace")}
+_SAFE_MODULES = ("torch._utils", "torch._tensor", "torch.storage", "torch.serialization", "torch.nn.parameter",
+                 "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric",
+                 "numpy.dtypes")
+
+
+def _restricted_pickle_module():
+    """A ``pickle_module`` for torch.load whose Unpickler resolves only tensor-rebuilding helpers, plain containers
+    and EasyDict: a checkpoint cannot name os.system / builtins.eval / arbitrary classes.  (torch's own
+    ``weights_only=True`` unpickler cannot be used: it refuses to fill dict subclasses such as EasyDict.)"""
+    import pickle
+
+    class RestrictedUnpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            ok = (module == "builtins" and name in _SAFE_BUILTINS) or (module, name) in _SAFE_EXACT or \
+                module in _SAFE_MODULES or (module == "torch" and (name.endswith("Storage") or name in ("Size", "device", "dtype")
+                                                                    or name.startswith(("float", "int", "uint", "bfloat", "complex", "bool"))))
+            if not ok:
+                raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is outside the allow-list")
+            return super().find_class(module, name)
+
+    mod = types.ModuleType("hudiff_amd._restricted_pickle")
+    mod.Unpickler = RestrictedUnpickler
+    mod.UnpicklingError = pickle.UnpicklingError
+    mod.load = lambda f, **kw: RestrictedUnpickler(f, **kw).load()
+    mod.loads = pickle.loads
+    mod.dump, mod.dumps, mod.Pickler = pickle.dump, pickle.dumps, pickle.Pickler
+    mod.__name__ = "pickle"
+    return mod
+
+
+def load_checkpoint(path, map_location="cpu", trust_pickle=None):
+    """torch.load(path) tolerant of EasyDict configs.
+
+    The file is read through a restricted unpickler (tensors, plain containers, numpy scalars and
+    ``easydict.EasyDict`` only), so that a ``--ckpt`` from an untrusted source cannot run code.  A checkpoint that
+    carries other pickled classes needs the unrestricted loader, which executes whatever the pickle says: opt in
+    with ``trust_pickle=True`` or ``HUDIFF_TRUST_CKPT=1`` for files you trust (the reference always loads that way,
+    antibody_scripts/sample.py:448)."""
+    import os
+    import pickle
     import torch
     _ensure_easydict()
-    return torch.load(path, map_location=map_location, weights_only=False)
+    if trust_pickle is None:
+        trust_pickle = os.environ.get("HUDIFF_TRUST_CKPT") == "1"
+    kw = {}
+    try:
+        import inspect
+        if "weights_only" in inspect.signature(torch.load).parameters:
+            kw["weights_only"] = False          # the restriction is ours (pickle_module); torch < 1.13 has no such keyword
+    except (TypeError, ValueError):
+        pass
+    if trust_pickle:
+        return torch.load(path, map_location=map_location, **kw)
+    try:
+        return torch.load(path, map_location=map_location, pickle_module=_restricted_pickle_module(), **kw)
+    except pickle.UnpicklingError as e:
+        raise RuntimeError(f"{path}: {e}.  If the file comes from a trusted source, re-run with HUDIFF_TRUST_CKPT=1 "
+                           "(unrestricted pickle).") from e
 
 
 def _strip_module(sd):

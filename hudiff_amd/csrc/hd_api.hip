@@ -81,7 +81,6 @@ struct Workspace {
     float *PW = nullptr, *YV = nullptr;                      // pruned last block: p_j rstd_j [B, nhead, 320], weighted input rows [B, nhead, D]
     int32_t *tokens = nullptr, *tokens0 = nullptr, *region = nullptr, *chain = nullptr, *order = nullptr, *T = nullptr;
     int capT = 0;
-    float* qnoise = nullptr; size_t qnoise_cap = 0;
     uint8_t *enc_masks = nullptr, *conv_masks = nullptr; size_t enc_cap = 0, conv_cap = 0;
     std::vector<void*> owned;
 };
@@ -113,6 +112,10 @@ struct HdModel {
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     float* side_vec = nullptr;
     float2* emb_stats = nullptr;      // [n_tokens] LayerNorm (mean, rstd) of each embedding row
+    // injected Exp(1) noise of the open session, [Tmax, B, 22] for the WHOLE batch (every lane indexes it by its row
+    // offset).  Owned by the model, not by a lane's workspace: a captured graph holds this pointer, so it is part of
+    // every lane's graph key and outlives any lane's workspace regrowth.
+    float* qnoise = nullptr; size_t qnoise_cap = 0;
     // Two independent "lanes" (stream + workspace + graph): hd_sample splits a batch into two halves that run
     // concurrently on their own streams.  Rows are independent, so there is no cross-lane dependency; one lane's
     // kernel tails / attention staging / launch gaps are filled by the other lane's kernels.
@@ -125,6 +128,7 @@ struct HdModel {
         hipGraphExec_t graph_exec = nullptr;
         int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
         int graph_qB = -1, graph_qoff = -1;
+        const float* graph_qptr = nullptr;           // the injected-noise buffer the captured sample_step_k reads
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
     } lane[HD_MAX_LANES];
     int cl = 0;                                      // lane the helper functions currently address
@@ -259,6 +263,7 @@ extern "C" void hd_destroy(HdModel* m) {
     if (m->blob) hipFree(m->blob);
     if (m->side_vec) hipFree(m->side_vec);
     if (m->emb_stats) hipFree(m->emb_stats);
+    if (m->qnoise) hipFree(m->qnoise);
     delete m;
 }
 
@@ -985,18 +990,18 @@ static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, 
     const bool prune = !(m->sflags & HD_NO_PRUNE);
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = ln.ws;
-    // the injected Exp(1) noise lives once, for the whole batch, in lane 0's workspace
+    // the injected Exp(1) noise lives once, for the whole batch, in the model (m->qnoise)
     hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
-                       ws.T, m->sTmax, m->s_has_q ? m->lane[0].ws.qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0);
+                       ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0);
     hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }
 
-extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
-                                    const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
-                                    uint64_t seed, uint64_t row0, const float* q_noise,
-                                    const uint8_t* enc_masks, const uint8_t* conv_masks) {
+static HdStatus sample_begin_impl(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                                  const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                                  uint64_t seed, uint64_t row0, const float* q_noise,
+                                  const uint8_t* enc_masks, const uint8_t* conv_masks) {
     if (!m || !tokens || !region || !T || (Tmax > 0 && !order)) return fail(HD_ERR_INVALID, "hd_sample_begin: null argument");
     if (!m->finalized) return fail(HD_ERR_STATE, "hd_sample_begin: call hd_finalize first");
     if (m->in_session) return fail(HD_ERR_STATE, "hd_sample_begin: session already open");
@@ -1041,14 +1046,33 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
         HIP_TRY(hipStreamSynchronize(ln.stream));          // chain_l is reused by the next lane
         {
             const size_t need = (size_t)Bl * (Tmax > 0 ? Tmax : 1);
-            if (need > (size_t)ws.capT) { HD_TRY(dalloc(ws, &ws.order, need)); ws.capT = (int)need; }
+            if (need > (size_t)ws.capT) {
+                if (ws.order) {                 // regrown: release the old buffer now, not at the next free_ws
+                    for (auto it = ws.owned.begin(); it != ws.owned.end(); ++it)
+                        if (*it == (void*)ws.order) { ws.owned.erase(it); break; }
+                    HIP_TRY(hipStreamSynchronize(ln.stream));
+                    hipFree(ws.order);
+                    ws.order = nullptr; ws.capT = 0;
+                    // a captured graph holds the old pointer
+                    if (ln.graph_exec) { hipGraphExecDestroy(ln.graph_exec); ln.graph_exec = nullptr; }
+                    if (ln.graph) { hipGraphDestroy(ln.graph); ln.graph = nullptr; }
+                    ln.graph_B = -1;
+                }
+                HD_TRY(dalloc(ws, &ws.order, need));
+                ws.capT = (int)need;
+            }
         }
         if (Tmax > 0) HIP_TRY(hipMemcpyAsync(ws.order, order + (size_t)off * Tmax, (size_t)Bl * Tmax * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
         HIP_TRY(hipMemcpyAsync(ws.T, T + off, (size_t)Bl * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
         if (l == 0 && q_noise && Tmax > 0) {
             const size_t n = (size_t)Tmax * B * 22;
-            HD_TRY(ensure_buf(m, &ws.qnoise, &ws.qnoise_cap, n));
-            HIP_TRY(hipMemcpyAsync(ws.qnoise, q_noise, n * sizeof(float), hipMemcpyHostToDevice, ln.stream));
+            if (n > m->qnoise_cap) {
+                for (auto& o : m->lane) if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+                if (m->qnoise) { hipFree(m->qnoise); m->qnoise = nullptr; m->qnoise_cap = 0; }
+                HIP_TRY(hipMalloc(&m->qnoise, n * sizeof(float)));
+                m->qnoise_cap = n;
+            }
+            HIP_TRY(hipMemcpyAsync(m->qnoise, q_noise, n * sizeof(float), hipMemcpyHostToDevice, ln.stream));
         }
         if (dm == DROP_INJECT && Tmax > 0) {
             const size_t ne = (size_t)Tmax * m->cfg.n_encoder_layers * B * m->L * m->d, nc = (size_t)Tmax * m->cfg.dual_layers * B * m->L * m->D;
@@ -1066,6 +1090,17 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
     m->s_row0 = row0;
     m->in_session = true;
     return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int32_t* region, const int32_t* chain,
+                                    const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
+                                    uint64_t seed, uint64_t row0, const float* q_noise,
+                                    const uint8_t* enc_masks, const uint8_t* conv_masks) {
+    const HdStatus s = sample_begin_impl(m, tokens, region, chain, order, T, B, Tmax, flags, seed, row0, q_noise, enc_masks, conv_masks);
+    if (s != HD_OK && m && !m->in_session) {     // a failure half-way through the lane loop must not leave lane state behind
+        m->cl = 0; m->nlanes = 1; m->sB = 0; m->timed = false;
+    }
+    return s;
 }
 
 extern "C" HdStatus hd_sample_restart(HdModel* m, uint64_t seed) {
@@ -1097,7 +1132,8 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
         if (!use_graph) continue;
         const uint32_t gflags = m->sflags & HD_NO_PRUNE;
         if (!ln.graph_exec || ln.graph_B != ln.B || ln.graph_flags != gflags || ln.graph_drop != dm || ln.graph_q != m->s_has_q ||
-            ln.graph_Tmax != m->sTmax || ln.graph_qB != m->sB || ln.graph_qoff != ln.row_off) {
+            ln.graph_Tmax != m->sTmax || ln.graph_qB != m->sB || ln.graph_qoff != ln.row_off ||
+            ln.graph_qptr != (m->s_has_q ? m->qnoise : nullptr)) {
             if (ln.graph_exec) { hipGraphExecDestroy(ln.graph_exec); ln.graph_exec = nullptr; }
             if (ln.graph) { hipGraphDestroy(ln.graph); ln.graph = nullptr; }
             HIP_TRY(hipStreamSynchronize(ln.stream));
@@ -1108,7 +1144,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
             if (e != hipSuccess) { m->cl = 0; return fail(HD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
             HIP_TRY(hipGraphInstantiate(&ln.graph_exec, ln.graph, nullptr, nullptr, 0));
             ln.graph_B = ln.B; ln.graph_flags = gflags; ln.graph_drop = dm; ln.graph_q = m->s_has_q; ln.graph_Tmax = m->sTmax;
-            ln.graph_qB = m->sB; ln.graph_qoff = ln.row_off;
+            ln.graph_qB = m->sB; ln.graph_qoff = ln.row_off; ln.graph_qptr = m->s_has_q ? m->qnoise : nullptr;
         }
     }
     for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipEventRecord(m->lane[l].ev0, m->lane[l].stream));

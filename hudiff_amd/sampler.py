@@ -35,11 +35,27 @@ class Job:
     parent: dict = field(default_factory=dict)
 
 
+def _id_runs(gids: np.ndarray, max_rows: int):
+    """Split positions 0..len(gids) into chunks of <= max_rows whose global row ids are consecutive (one device
+    launch keys its rows as row0 + b)."""
+    s = 0
+    while s < len(gids):
+        e = s + 1
+        while e < len(gids) and e - s < max_rows and gids[e] == gids[e - 1] + 1:
+            e += 1
+        yield s, e
+        s = e
+
+
 def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes: int = 1,
-                device_batch: int = 256, dropout: str = "faithful", q_noise=None, all_ranks: bool = False) -> np.ndarray:
+                device_batch: int = 256, dropout: str = "faithful", q_noise=None, all_ranks: bool = False,
+                job_ids: Optional[Sequence[int]] = None) -> np.ndarray:
     """Sample ``replicas`` rows per job; returns int32 [len(jobs), passes, replicas, L] on rank 0 (every rank
     when single-process or ``all_ranks``).  ``passes`` > 1 re-runs the loop over the already filled tokens, which is what the
-    reference's ``while sample_number > 0`` loop does (sample.py:499, nanosample.py:316)."""
+    reference's ``while sample_number > 0`` loop does (sample.py:499, nanosample.py:316).
+
+    ``job_ids``: the id each job's noise is keyed by (default: its position in ``jobs``).  Row (job, replica) draws
+    its noise as global row ``job_ids[job] * replicas + replica``, whatever else is in the batch."""
     L = model.max_len
     n_rows = len(jobs) * replicas
     rank, world, _ = D.env_rank_world()
@@ -47,9 +63,12 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
     is_ab = model.kind == "ab"
     Tmax = max([len(j.loc) for j in jobs] + [1])
     out = np.zeros((passes, hi - lo, L), np.int32)
-    for s in range(lo, hi, device_batch):
-        e = min(s + device_batch, hi)
-        ids = np.arange(s, e)
+    jid = np.arange(len(jobs), dtype=np.int64) if job_ids is None else np.asarray(job_ids, dtype=np.int64)
+    pos = np.arange(lo, hi)                                      # positions in the packed (job-major) row list
+    gids = jid[pos // replicas] * replicas + pos % replicas      # the ids the noise is keyed by
+    for cs, ce in _id_runs(gids, device_batch):
+        ids = pos[cs:ce]
+        s, e = int(ids[0]), int(ids[-1]) + 1
         jb = [jobs[i // replicas] for i in ids]
         tok = np.stack([j.tokens if np.ndim(j.tokens) == 1 else j.tokens[i % replicas]
                         for i, j in zip(ids, jb)]).astype(np.int32)
@@ -61,7 +80,7 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
             T[r] = len(j.loc)
         chain = np.array([j.chain[0] for j in jb] + [j.chain[1] for j in jb], np.int32) if is_ab else None
         for p in range(passes):
-            tok = model.sample(tok, reg, chain, order, T, seed=seed + 1000003 * p, row0=s, dropout=dropout,
+            tok = model.sample(tok, reg, chain, order, T, seed=seed + 1000003 * p, row0=int(gids[cs]), dropout=dropout,
                                q_noise=None if q_noise is None else q_noise[p][:, s:e])
             out[p, s - lo:e - lo] = tok
     gathered = [D.gather_rows(out[p], n_rows, L, all_ranks) for p in range(passes)]
@@ -86,8 +105,10 @@ def sample_jobs_with_retry(model, jobs: Sequence[Job], replicas: int, seed: int,
     while active:
         sub = [Job(tokens=jobs[j].tokens if state[j]["tokens"] is None else state[j]["tokens"], region=jobs[j].region,
                    loc=jobs[j].loc, chain=jobs[j].chain, name=jobs[j].name) for j in active]
+        # noise is keyed by the ORIGINAL job index: a sequence's samples do not depend on which other inputs were
+        # accepted earlier (or are in the file at all)
         res = sample_jobs(model, sub, replicas, seed + 1000003 * sweep, device_batch=device_batch, dropout=dropout,
-                          all_ranks=True)
+                          all_ranks=True, job_ids=active)
         still = []
         for a, j in enumerate(active):
             st = state[j]

@@ -66,9 +66,14 @@ def test_antibody_cli_end_to_end(tmp_path):
     fa = open(os.path.join(log_dir, "sample_identity.fa")).read().splitlines()
     assert fa[0] == ">v007human0 VH" and fa[2] == ">v007human0 VL" and len(fa) == 4 * 5
     # same seed -> same CSV body (noise is counter-based, independent of device batching)
-    out2 = cli.main(["--ckpt", str(ckdir / "hudiffab.pt"), "--data_fpath", str(csv), "--numbered_fpath", str(nb),
+    # (second run under another checkpoint parent: the log-dir name has one-second resolution, sample.py:434-443)
+    ckdir2 = tmp_path / "run2" / "checkpoints"
+    ckdir2.mkdir(parents=True)
+    (ckdir2 / "hudiffab.pt").write_bytes((ckdir / "hudiffab.pt").read_bytes())
+    out2 = cli.main(["--ckpt", str(ckdir2 / "hudiffab.pt"), "--data_fpath", str(csv), "--numbered_fpath", str(nb),
                      "--batch_size", "3", "--seed", "5", "--device_batch", "4"])
-    assert open(out2).read() == open(out).read() or os.path.dirname(out2) == log_dir
+    assert os.path.dirname(out2) != log_dir
+    assert open(out2).read() == open(out).read()
 
 
 def test_nanobody_cli_end_to_end(tmp_path):

@@ -112,6 +112,34 @@ def test_two_lanes_equal_one_lane(micro):
     assert np.array_equal(two[36:40], want)          # rows of the second lane against the oracle
 
 
+def test_cached_graphs_survive_workspace_regrowth(micro):
+    """every lane's captured graph reads the injected-noise buffer; regrowing lane 0's workspace (a larger
+    hd_forward, a one-lane session) or the noise buffer itself between two identical two-lane calls must not leave a
+    lane replaying a graph that points at freed memory."""
+    from hudiff_amd import synthetic as S
+    B = 128
+    batch = S.synthetic_batch(micro["kind"], B, seed=44)
+    T = np.minimum(batch["T"], 5)
+    q = np.random.default_rng(1).exponential(size=(batch["order"].shape[1], B, 22)).astype(np.float32)
+    args = (batch["tokens"], batch["region"], batch["chain"], batch["order"], T)
+    m = micro["m0"]
+    first = m.sample(*args, q_noise=q, lanes=2)
+    m(batch["tokens"][:96], batch["region"][:96],
+      None if batch["chain"] is None else np.concatenate([batch["chain"][:96], batch["chain"][B:B + 96]]))   # lane 0: 64 -> 96 rows
+    assert np.array_equal(m.sample(*args, q_noise=q, lanes=2), first)
+    m.sample(*args, q_noise=q, lanes=1)                                                  # lane 0: -> 128 rows
+    assert np.array_equal(m.sample(*args, q_noise=q, lanes=2), first)
+    # a longer schedule regrows the noise buffer and the order buffers, then the original call again
+    order2 = np.concatenate([batch["order"], batch["order"]], axis=1)
+    q2 = np.concatenate([q, q], axis=0)
+    m.sample(batch["tokens"], batch["region"], batch["chain"], order2, T, q_noise=q2, lanes=2)
+    assert np.array_equal(m.sample(*args, q_noise=q, lanes=2), first)
+    want = ho.sample(micro["o0"], batch["tokens"][70:73], batch["region"][70:73],
+                     None if batch["chain"] is None else np.concatenate([batch["chain"][70:73], batch["chain"][B + 70:B + 73]]),
+                     batch["order"][70:73], T[70:73], q_noise=q[:, 70:73])
+    assert np.array_equal(first[70:73], want)
+
+
 def test_sampling_with_reference_dropout_masks(micro):
     z = load_golden(f"micro_{micro['kind']}_sample_dropout.npz")
     B, loc = z["tokens"].shape[0], z["loc"]

@@ -160,6 +160,53 @@ def test_retry_loop_matches_reference_walk(monkeypatch):
             assert n_accept > 0 and any(len(v) > 1 for v in sweeps.values()) or tries == 1
 
 
+def test_retry_rows_are_keyed_by_original_job_index():
+    """A sequence's noise ids must not depend on which other inputs are still active: every device launch
+    of a re-sweep keys its rows as original_job * replicas + replica."""
+    from hudiff_amd import sampler
+    jobs = _jobs(6)
+    replicas = 2
+    for i, j in enumerate(jobs):                       # tag every job's rows so the fake model can recognise them
+        j.tokens = j.tokens.copy()
+        j.tokens[int(jobs[0].loc[0])] = i % 20
+
+    class Recording(FakeModel):
+        calls = []
+
+        def sample(self, tokens, region, chain, order, T, *, seed=0, row0=0, **kw):
+            tag = tokens[:, int(jobs[0].loc[0])]
+            tag = np.where(tag >= 100, tag - 100, tag)
+            self.calls.append((seed, [int(row0) + b for b in range(tokens.shape[0])], [int(t) for t in tag]))
+            out = super().sample(tokens, region, chain, order, T, seed=seed, row0=row0, **kw)
+            out[:, int(jobs[0].loc[0])] = tag + 100            # keep the tag through the sweeps
+            return out
+
+    accept = lambda row: int(row[int(jobs[0].loc[0])]) - 100 in (0, 2, 5)       # jobs 1, 3, 4 keep failing
+    Recording.calls = []
+    sampler.sample_jobs_with_retry(Recording(), jobs, replicas, 7, want=1, tries=6, accept=accept, device_batch=3)
+    assert len({c[0] for c in Recording.calls}) == 3                             # three sweeps
+    for seed, gids, tags in Recording.calls:
+        assert len(gids) <= 3
+        for g, t in zip(gids, tags):
+            assert g // replicas == t, (seed, gids, tags)                        # global id = original job * replicas + r
+    later = [t for seed, g, tg in Recording.calls if seed != 7 for t in tg]
+    assert sorted(set(later)) == [1, 3, 4]
+
+
+def test_checkpoint_loader_refuses_foreign_pickles(tmp_path):
+    torch = pytest.importorskip("torch")
+    from hudiff_amd import checkpoint as ck
+
+    class Evil:
+        def __reduce__(self):
+            return (os.path.join, ("a", "b"))           # any callable outside the allow-list
+    p = tmp_path / "evil.pt"
+    torch.save({"model": {}, "x": Evil()}, p)
+    with pytest.raises(RuntimeError, match="allow-list"):
+        ck.load_checkpoint(str(p))
+    assert ck.load_checkpoint(str(p), trust_pickle=True)["x"] == os.path.join("a", "b")
+
+
 def test_checkpoint_envelopes(tmp_path):
     torch = pytest.importorskip("torch")
     from hudiff_amd import checkpoint as ck
