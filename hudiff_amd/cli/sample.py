@@ -7,8 +7,10 @@ row, 'mouse,{name},{h},{l}' followed by 'humanization,{name}human_sample,{h},{l}
 
 Differences, all forced by what is absent offline: IMGT numbering uses anarci/abnumber when
 importable and otherwise the built-in slotter (``--numbering``; ``--numbered_fpath`` accepts pre-numbered
-residues); ``--sample_method inpaint`` and
-``--traditional_method`` (abnumber CDR grafting onto human germlines) raise; the similarity
+residues); ``--sample_method inpaint`` grafts with abnumber when importable and otherwise takes pre-grafted chains
+from ``--grafted_fpath`` (everything after the graft -- placement of the identity positions, mask, loc -- is
+hudiff_amd.inputs.antibody_inpaint_row, pinned against the reference's batch_inpaint_input_element);
+``--traditional_method`` (pure abnumber CDR grafting, no model) raises; the similarity
 search scores identity over the aligned IMGT slots instead of an abnumber alignment; noise comes from the
 library's counter-based generator keyed by (seed, global row, step), not torch's global mt19937 stream.
 """
@@ -49,6 +51,10 @@ def build_parser():
     # additions
     p.add_argument("--numbered_fpath", type=str, default=None,
                    help="JSON-lines file with pre-numbered IMGT residues, one object per mouse row of --data_fpath")
+    p.add_argument("--grafted_fpath", type=str, default=None,
+                   help="--sample_method inpaint without abnumber: JSON-lines file, one object per mouse row, "
+                        '{"h": {IMGT position: residue of the CDR-grafted VH}, "l": {...}, "identity_h": [positions kept], '
+                        '"identity_l": [...], "l_chain": "K"|"L"} (what graft_chain, sample.py:209-226, returns)')
     p.add_argument("--numbering", choices=["auto", "anarci", "builtin"], default="auto",
                    help="IMGT numbering of raw sequences: anarci+abnumber as the reference (auto: when importable), "
                         "else the built-in slotter hudiff_amd/numbering.py")
@@ -89,12 +95,36 @@ def select_most_similar(parent_tokens, replica_tokens):
     return best
 
 
+def traditional_main(args):
+    """sample.py:539-576: CDR grafting only (abnumber), one 'humanization' row per mouse row and no 'mouse' rows; the log
+    directory sits next to the data file."""
+    data_sample = "humab" if "humab" in args.data_fpath else ("putative" if "putative" in args.data_fpath else "lab")
+    log_dir = get_new_log_dir(root=os.path.dirname(args.data_fpath), prefix=f"{data_sample}_cdr_graft_back_mutation_{args.back_mutation}")
+    save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")
+    get_logger("test", log_dir)
+    human_rows = []
+    with open(save_fpath, "a", encoding="UTF-8") as f:
+        f.write("Specific,name,hseq,lseq,\n")
+        for line in read_mouse_rows(args.data_fpath).itertuples():
+            g_h, g_l = I.cdr_pair_grafting(line.h_seq, line.l_seq, back_mutation=bool(args.back_mutation))
+            f.write(f"humanization,{line.name}human_sample,{g_h},{g_l}\n")
+            human_rows.append((g_h, g_l))
+    records = []
+    for i, (g_h, g_l) in enumerate(human_rows):
+        records += [(args.fa_version + "human" + f"{i}", "VH", g_h), (args.fa_version + "human" + f"{i}", "VL", g_l)]
+    write_fasta_2line(records, os.path.join(log_dir, "sample_identity.fa"))
+    if args.structure:
+        split_fasta_for_save(save_fpath, human_rows)
+    return save_fpath
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.traditional_method:
-        raise NotImplementedError("--traditional_method (abnumber CDR grafting, sample.py:539-576) is outside the hot path")
-    if args.sample_method != "FR":
-        raise NotImplementedError("--sample_method inpaint needs abnumber CDR grafting (sample.py:209-310); §8f 'next'")
+        return traditional_main(args)
+    if args.sample_method == "inpaint" and not args.grafted_fpath and I.numbering_backend("auto") != "anarci":
+        raise RuntimeError("--sample_method inpaint grafts the CDRs onto a human germline with abnumber (sample.py:209-226), "
+                           "which is not installed here: supply the grafted chains with --grafted_fpath")
     rank, world, local_rank = D.env_rank_world()
     D.init_process_group()
     seed_all(args.seed)
@@ -121,8 +151,31 @@ def main(argv=None):
     numbered = load_numbered(args.numbered_fpath) if args.numbered_fpath else None
     if numbered is not None and len(numbered) != len(mouse_df.index):
         raise ValueError(f"{args.numbered_fpath}: {len(numbered)} rows for {len(mouse_df.index)} mouse rows")
+    grafted = load_numbered(args.grafted_fpath) if (args.sample_method == "inpaint" and args.grafted_fpath) else None
+    if grafted is not None and len(grafted) != len(mouse_df.index):
+        raise ValueError(f"{args.grafted_fpath}: {len(grafted)} rows for {len(mouse_df.index)} mouse rows")
     jobs = []
     for idx, line in enumerate(mouse_df.itertuples()):
+        if args.sample_method == "inpaint":
+            # sample.py:486-489 batch_inpaint_input_element: the graft's identity positions stay, the rest of the
+            # CDR-IMGT framework is sampled.  The similarity search still compares with the MOUSE chains (:524).
+            if grafted is not None:
+                g = grafted[idx]
+                gh, ih, gl, il, l_type = g["h"], g["identity_h"], g["l"], g["identity_l"], g.get("l_chain", "K")
+            else:
+                gh, ih, _ = I.graft_chain(line.h_seq)
+                gl, il, l_type = I.graft_chain(line.l_seq)
+            tok, reg, chain, loc = I.antibody_inpaint_row(gh, gl, ih, il, l_type, pad_region=pad_region)
+            if numbered is not None:
+                h_dict, l_dict = numbered[idx]["h"], numbered[idx]["l"]
+            else:
+                h_dict, l_dict = I.number_sequence(line.h_seq, args.numbering)[0], I.number_sequence(line.l_seq, args.numbering)[0]
+            parent = np.array(I._TK.seq2idx(I.slot_residues(h_dict, "H") + I.slot_residues(l_dict, "L")))
+            if args.sample_order == "shuffle":
+                np.random.shuffle(loc)
+            jobs.append(Job(tokens=tok, region=reg, loc=loc, chain=chain, name=str(line.name),
+                            parent={"h": line.h_seq, "l": line.l_seq, "tokens": parent}))
+            continue
         if numbered is None:
             h_dict, h_type = I.number_sequence(line.h_seq, args.numbering)
             l_dict, l_type = I.number_sequence(line.l_seq, args.numbering)

@@ -64,9 +64,10 @@ def slot_residues(seq_dict: Dict[str, str], chain: str, quiet: bool = True):
             out[idx] = value
         elif not quiet:
             n = int(re.findall(r"\d+", key)[0])
-            where = "CDR has problem." if (27 <= n <= 38 or 56 <= n <= 65 or 105 <= n <= 117) else \
-                f"Position {key} is not in predefine dict, which can be ignored."
-            print(("Heavy " if chain == "H" else "Light ") + where)
+            if 27 <= n <= 38 or 56 <= n <= 65 or 105 <= n <= 117:
+                print(("Heavy" if chain == "H" else "Light") + " CDR has problem.")
+            else:
+                print(("H" if chain == "H" else "L") + f" Position {key} is not in predefine dict, which can be ignored.")
     return out
 
 
@@ -80,6 +81,62 @@ def antibody_row(h_dict, l_dict, l_chain_type: str, finetune: bool = True, pad_r
     else:
         mask = np.array(T.HEAVY_CDR_KABAT_NO_VERNIER + T.LIGHT_CDR_KABAT_NO_VERNIER) == 0
         mask = mask & ~((tok == _TK.idx_pad) & mask)          # framework gap slots are not sampled (:161-165)
+    loc = np.arange(T.AB_LEN)[mask]
+    tok = tok.copy()
+    tok[mask] = _TK.idx_msk
+    chain = (_TK.chain_type_idx("H"), _TK.chain_type_idx(l_chain_type))
+    return tok.astype(np.int32), T.ab_region(pad_region).astype(np.int32), chain, loc
+
+
+def graft_chain(aa_seq: str):
+    """sample.py:209-226 ``graft_chain`` -- needs abnumber (its human-germline database does the grafting): CDRs of
+    ``aa_seq`` on the closest human germline -> (numbered residues of the graft, identity position names, chain type).
+    Without abnumber pre-grafted input can be supplied instead (``--grafted_fpath`` of hudiff_amd.cli.sample)."""
+    try:
+        from abnumber import Chain
+    except ImportError as e:
+        raise RuntimeError("CDR grafting needs `abnumber` (not installed here); pass --grafted_fpath with "
+                           "pre-grafted numbered chains instead") from e
+    seq_chain = Chain(aa_seq, scheme="imgt")
+    grafted = seq_chain.graft_cdrs_onto_human_germline()
+    align = seq_chain.align(grafted)
+    identity = []
+    for pos in align.positions:
+        if pos.is_in_cdr():
+            identity.append(str(pos)[1:])
+        else:
+            a1, a2 = align[pos]
+            if a1 == a2:
+                identity.append(str(pos)[1:])
+    seq_dict, chain_type = number_sequence(grafted.seq, "anarci")
+    return seq_dict, identity, chain_type
+
+
+def cdr_pair_grafting(mouse_h_seq: str, mouse_l_seq: str, back_mutation: bool = False, scheme: str = "kabat"):
+    """sample.py:370-376 (``--traditional_method``): plain CDR grafting of both chains onto their closest human
+    germlines with abnumber, optionally back-mutating the Vernier zone.  No model involved."""
+    try:
+        from abnumber import Chain
+    except ImportError as e:
+        raise RuntimeError("--traditional_method is abnumber's CDR grafting (sample.py:370-376); `abnumber` is not "
+                           "installed here") from e
+    h = Chain(mouse_h_seq, scheme=scheme).graft_cdrs_onto_human_germline(backmutate_vernier=back_mutation)
+    l = Chain(mouse_l_seq, scheme=scheme).graft_cdrs_onto_human_germline(backmutate_vernier=back_mutation)
+    return h.seq, l.seq
+
+
+def antibody_inpaint_row(h_dict, l_dict, identity_h, identity_l, l_chain_type: str, pad_region: int = 0):
+    """``--sample_method inpaint`` after grafting (sample.py:229-310 for one replica): ``h_dict`` / ``l_dict`` are the
+    numbered residues of the CDR-GRAFTED chains (mouse CDRs on the closest human germline, ``graft_chain``
+    sample.py:209-226 -- abnumber's germline database, not part of this package) and ``identity_*`` the position names
+    kept from the graft: all CDR positions plus the framework positions where graft and mouse agree.  Only those
+    residues are placed; every other CDR-IMGT framework slot -- mismatches AND slots the graft leaves empty -- is masked
+    and sampled (:291-299).  -> tokens[291] (masked), region[291], chain ids, loc."""
+    keep_h, keep_l = set(identity_h), set(identity_l)
+    slots = slot_residues({k: v for k, v in h_dict.items() if k in keep_h}, "H") + \
+        slot_residues({k: v for k, v in l_dict.items() if k in keep_l}, "L")
+    tok = _TK.seq2idx(slots)
+    mask = (np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0) & (tok == _TK.idx_pad)
     loc = np.arange(T.AB_LEN)[mask]
     tok = tok.copy()
     tok[mask] = _TK.idx_msk

@@ -34,7 +34,16 @@ _DUMMY_ROOTS = (
 _DUMMY_EXACT = ("dataset.abnativ_alignment.align_and_clean",)
 
 
-class _Anything:
+class _AnythingMeta(type):
+    """Class-level attribute sink (``from Bio.Align import substitution_matrices; substitution_matrices.load``)."""
+
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _Anything(metaclass=_AnythingMeta):
     """Attribute sink: any attribute / call / subscript yields another sink."""
 
     def __init__(self, *a, **k):

@@ -49,6 +49,25 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+def load_deep(kind):
+    """tests/golden/deep_{kind}.npz (oracle/make_golden_deep.py): production depth / heads at small width.  Weights are
+    regenerated from the recorded seed and checked against the recorded SHA-256.  -> (fixture, config, state_dict)"""
+    import hashlib
+    from hudiff_amd import synthetic as S
+    z = np.load(os.path.join(GOLDEN, f"deep_{kind}.npz"))
+    cfg = {}
+    for k, v in zip(z["config_keys"], z["config_vals"]):
+        v = str(v)
+        cfg[str(k)] = v if k == "activation" else (float(v) if k == "dropout" else int(v))
+    sd = S.random_state_dict(kind, cfg, seed=int(z["weight_seed"]))
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k], dtype=np.float32).tobytes())
+    assert h.hexdigest() == str(z["weight_sha256"]), "regenerated weights differ from the ones the reference ran with"
+    return z, cfg, sd
+
+
 def unpack_masks(z, key):
     shape = tuple(int(x) for x in z[key.replace("masks", "shape")])
     return np.unpackbits(z[key])[: int(np.prod(shape))].reshape(shape)

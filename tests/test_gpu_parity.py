@@ -210,6 +210,37 @@ def test_empty_batch_and_errors(micro, hip):
 
 
 @pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_deep_golden_vs_reference(hip, kind):
+    """Production depth and head structure (6 + 6 ByteNet blocks = dilations 1..32, 5 SelfAttBlocks, 8 heads) at small
+    width, against vectors the REFERENCE's classes produced (oracle/make_golden_deep.py): logits with dropout off,
+    logits under the reference's recorded dropout masks, and a 16-step trace under its recorded Exp(1) noise."""
+    from conftest import load_deep
+    z, cfg, sd = load_deep(kind)
+    chain = z["chain"] if z["chain"].size else None
+    m0, m1 = _mk(hip, kind, cfg, sd), _mk(hip, kind, dict(cfg, dropout=float(z["p"])), sd)
+    try:
+        err = np.abs(m0(z["tokens"], z["region"], chain) - z["logits"]).max()
+        assert err < LOGIT_TOL, err
+        got = m1(z["tokens"], z["region"], chain, dropout="inject", enc_masks=unpack_masks(z, "enc_masks"),
+                 conv_masks=unpack_masks(z, "conv_masks"))
+        err = np.abs(got - z["logits_dropout"]).max()
+        assert err < LOGIT_TOL, err
+        B, loc = z["s_tokens"].shape[0], z["s_loc"]
+        s_chain = z["s_chain"] if z["s_chain"].size else None
+        for graph in (True, False):
+            out = m0.sample(z["s_tokens"], z["s_region"], s_chain, np.repeat(loc[None], B, 0), np.full(B, len(loc)),
+                            q_noise=z["q"], graph=graph)
+            assert np.array_equal(out, z["final"])
+        tokens = z["s_tokens"].copy()                                   # teacher-forced per-step logits
+        for t, slot in enumerate(loc):
+            lg = m0(tokens, z["s_region"], s_chain)[:, slot, :22]
+            assert np.abs(lg - z["step_logits"][t]).max() < LOGIT_TOL, t
+            tokens[:, slot] = z["step_sampled"][t]
+    finally:
+        m0.close(); m1.close()
+
+
+@pytest.mark.parametrize("kind", ["ab", "nb"])
 def test_production_config_forward_vs_oracle(hip, kind):
     """Full-width architecture (configs/antibody_train.yml / heavy_train.yml), random weights, small B."""
     from hudiff_amd import synthetic as S

@@ -245,6 +245,23 @@ def test_cli_flags_and_tags():
     assert nano_cli.sample_tag(n) == "2023_shuffle_nanobert_gen_not_equal_pretrain"
 
 
+def test_traditional_method_layout(tmp_path, monkeypatch):
+    """--traditional_method (sample.py:539-576): grafting itself is abnumber's; the CSV / FASTA / log-dir layout is ours."""
+    csv = tmp_path / "humab_x.csv"
+    csv.write_text("type,name,h_seq,l_seq\nmouse,a1," + H_SEQ + "," + L_SEQ + "\nhuman,a1,AAA,CCC\nmouse,b2," + H_SEQ[1:] + "," + L_SEQ + "\n")
+    with pytest.raises(RuntimeError, match="abnumber"):
+        ab_cli.main(["--data_fpath", str(csv), "--traditional_method", "1"])
+    calls = []
+    monkeypatch.setattr(I, "cdr_pair_grafting", lambda h, l, back_mutation=False, scheme="kabat": (calls.append(back_mutation), ("G" + h, "G" + l))[1])
+    out = ab_cli.main(["--data_fpath", str(csv), "--traditional_method", "1"])
+    assert os.path.dirname(os.path.dirname(out)) == str(tmp_path)
+    assert re.match(r"humab_cdr_graft_back_mutation_True_\d{4}_", os.path.basename(os.path.dirname(out))) and calls == [True, True]
+    assert open(out).read().splitlines() == ["Specific,name,hseq,lseq,", f"humanization,a1human_sample,G{H_SEQ},G{L_SEQ}",
+                                             f"humanization,b2human_sample,G{H_SEQ[1:]},G{L_SEQ}"]
+    fa = open(os.path.join(os.path.dirname(out), "sample_identity.fa")).read().splitlines()
+    assert fa[0] == ">v007human0 VH" and fa[1] == "G" + H_SEQ and len(fa) == 8
+
+
 def test_fasta_writers(tmp_path):
     from hudiff_amd.cli.common import write_fasta_2line, write_fasta_wrapped
     p = tmp_path / "a.fa"
