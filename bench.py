@@ -6,12 +6,13 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one complete T-step humanization sample of one batch of B = 256 independent rows per GPU
-(BASELINE.json configs[1]: HuDiff-Ab, HuAb348-shaped inputs, batch 256, 1 x MI355X): ~155 denoiser
-forwards of the 39.8 M-parameter AntiTFNet over 291 slots + the exponential-race resampling, with
-inference-time dropout as the reference runs it.  Inputs are synthetic (no ANARCI, no
-released checkpoint offline): HuAb348-shaped pre-slotted rows and seeded random weights of the exact
-production architecture.  Rows shard across GPUs with no data-path collective; one RCCL gather of the
-final int32 tokens ends the job (weak scaling: 256 rows per GPU).
+(BASELINE.json configs[1]: HuDiff-Ab on HuAb348, batch 256, 1 x MI355X): up to 154 denoiser forwards of the
+39.8 M-parameter AntiTFNet over 291 slots + the exponential-race resampling, with inference-time dropout as
+the reference runs it.  Rows are the 348 HuAb348 mouse pairs (pre-slotted integer fixture tests/golden/real_rows.npz,
+scripts/make_real_rows.py; global row g = pair g % 348, replica g // 348, ragged T = 141..154) -- `--data synthetic`
+gives the HuAb348-shaped random rows of round 1 instead.  Weights are seeded random weights of the exact production
+architecture (no released checkpoint offline).  Rows shard across GPUs with no data-path collective; one RCCL gather
+of the final int32 tokens ends the job (weak scaling: 256 rows per GPU).
 
 Timed region: inputs already resident in HBM (hd_sample_begin uploaded them); K x [restore tokens
 device-side, re-key noise, run all T steps]; bracketed by barrier + device synchronise on both sides,
@@ -45,9 +46,15 @@ def parse():
     ap.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     ap.add_argument("--max-t", type=int, default=0, help="truncate every row to this many denoiser steps "
                     "(profiling aid; the JSON line is then marked truncated and is NOT the metric)")
+    ap.add_argument("--data", choices=["auto", "real", "synthetic"], default="auto",
+                    help="real = rows of the reference's evaluation set (HuAb348 / VHH, tests/golden/real_rows.npz); "
+                         "auto = real when the fixture is present")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the 'best batch' CPU leg (B = 1 is always timed too)")
+    ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--traffic", choices=["auto", "live", "file", "off"], default="auto",
+                    help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a 4-step run of "
+                         "this script in a subprocess after the timed region; file = profiles/r02/pmc_traffic.json")
     ap.add_argument("--cpu-impl", choices=["auto", "torch", "numpy"], default="auto",
                     help="CPU baseline on the oracle's PyTorch-CPU variant (auto: when torch is importable) or on numpy")
     ap.add_argument("--no-graph", action="store_true")
@@ -56,13 +63,40 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto"):
+def physical_cores():
+    """Physical cores of the host ((physical id, core id) pairs of /proc/cpuinfo), logical CPUs."""
+    logical = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return (len(seen) or logical), logical
+    except OSError:
+        return logical, logical
+
+
+def make_batch(kind, B, mode, row0, data):
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import synthetic as S
+    if data == "real" or (data == "auto" and E.available()):
+        return E.eval_batch("huab348" if kind == "ab" else "vhh", B, mode=mode, row0=row0, seed=2023), True
+    return S.synthetic_batch(kind, B, seed=2023, mode=mode, row0=row0), False
+
+
+def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="auto"):
     """The oracle (CPU port of the reference algorithm) on the host cores, bounded sample.  SURVEY.md §8d: the build's
-    CPU restatement, on PyTorch-CPU kernels where torch is present (oracle/hudiff_oracle_torch.py), else on numpy."""
+    CPU restatement, on PyTorch-CPU kernels where torch is present (oracle/hudiff_oracle_torch.py), else on numpy; timed
+    at B = 1 (the reference CLI's default --batch_size) and at a larger batch; `value` is the better of the two."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hudiff_oracle as ho
-    from hudiff_amd import synthetic as S
-    batch = S.synthetic_batch(kind, rows, seed=2023, mode=mode)
+    batch, _ = make_batch(kind, rows, mode, 0, data)
     net, name, threads = None, "numpy+OpenBLAS", None
     if impl in ("auto", "torch"):
         try:
@@ -74,39 +108,91 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto"):
                 raise
     if net is None:
         net = ho.OracleNet(kind, cfg, sd)
-    T = np.minimum(batch["T"], steps + 1)
-    ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, 1),
-              seed=1, dropout_mode="philox")                                   # warm-up (threads, caches)
+    phys, logical = physical_cores()
+
+    def run(n_rows, n_steps):
+        ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:n_rows], batch["chain"][rows:rows + n_rows]])
+        t0 = time.perf_counter()
+        ho.sample(net, batch["tokens"][:n_rows], batch["region"][:n_rows], ch, batch["order"][:n_rows],
+                  np.minimum(batch["T"][:n_rows], n_steps), seed=1, dropout_mode="philox")
+        return time.perf_counter() - t0
+
+    run(rows, 1)                                                               # warm-up (threads, caches)
     if threads is not None:
-        # many-core hosts oversubscribe these matrix sizes (256 logical CPUs: 0.035 sequences/s on 128 threads, 0.145 on 16,
-        # scripts/cpu_threads_probe.py): one step per candidate thread count, the timed sample runs on the fastest
+        # many-core hosts oversubscribe these matrix sizes (256 logical CPUs: 0.035 sequences/s on 128 threads, 0.145 on 16):
+        # one step per candidate thread count -- up to ALL physical cores -- the timed sample runs on the fastest
         import torch
         best = None
-        for n in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
+        for n in sorted({8, 16, 32, min(64, phys), phys}):
             torch.set_num_threads(n)
-            t0 = time.perf_counter()
-            ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, 1),
-                      seed=1, dropout_mode="philox")
-            dtn = time.perf_counter() - t0
+            dtn = run(rows, 1)
             if best is None or dtn < best[0]:
                 best = (dtn, n)
         threads = best[1]
         torch.set_num_threads(threads)
-        name += f" (best of 8/16/32/64 threads on {os.cpu_count()} logical CPUs)"
-    t0 = time.perf_counter()
-    ho.sample(net, batch["tokens"], batch["region"], batch["chain"], batch["order"], np.minimum(T, steps),
-              seed=1, dropout_mode="philox")
-    dt = time.perf_counter() - t0
-    per_step = dt / steps
+        name += f" (fastest of 8/16/32/64/{phys} threads)"
+    dt_b = run(rows, steps)
+    steps1 = max(2, steps // 2)
+    run(1, 1)
+    dt_1 = run(1, steps1)
     if threads is None:
         try:
             from threadpoolctl import threadpool_info
             threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
         except Exception:
             threads = os.cpu_count() or 1
-    return {"value": rows / (per_step * mean_T), "unit": "sequences/s", "cores": int(threads), "kind": "port",
-            "sample": f"oracle restatement of the reference loop on {name}, {rows} rows x {steps} denoiser steps with philox "
-                      f"dropout in {dt:.1f} s, extrapolated to the mean T = {mean_T:.1f} steps per sequence"}
+    v_b = rows / (dt_b / steps * mean_T)
+    v_1 = 1.0 / (dt_1 / steps1 * mean_T)
+    return {"value": max(v_b, v_1), "unit": "sequences/s", "cores": int(threads), "kind": "port",
+            "physical_cores": phys, "logical_cpus": logical, "value_batch_1": v_1, f"value_batch_{rows}": v_b,
+            "sample": f"oracle restatement of the reference loop on {name}; host has {phys} physical cores / {logical} logical "
+                      f"CPUs, {threads} threads used; {rows} rows x {steps} denoiser steps in {dt_b:.1f} s and 1 row x {steps1} "
+                      f"steps in {dt_1:.1f} s (B = 1 is the reference CLI's default), philox dropout, extrapolated to the "
+                      f"mean T = {mean_T:.1f} steps per sequence"}
+
+
+def live_traffic(args, kind, mode, n_steps=4):
+    """HBM-side bytes per denoiser step from rocprofv3 PMC passes of THIS script (FETCH_SIZE and WRITE_SIZE in separate
+    passes, MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B;
+    unit KB).  Counted from the first token gather on (the once-per-batch static branch is excluded)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="hudiff_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--kind", kind, "--mode", mode, "--batch", str(args.batch),
+                   "--dropout", args.dropout, "--data", args.data, "--steps", "1", "--warmup", "0", "--max-t", str(n_steps),
+                   "--no-cpu-baseline", "--lanes", "1", "--traffic", "off"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            rows = [r for f in files for r in csv.DictReader(open(f))]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            started, acc = False, 0.0
+            for r in rows:
+                started = started or "embed_tokens_k" in r["Kernel_Name"]
+                if started and r["Counter_Name"] == counter:
+                    acc += float(r["Counter_Value"])
+            tot[counter] = acc
+    except Exception as e:                 # profiler absent / refused: the bench line must still appear
+        sys.stderr.write(f"[bench] live PMC traffic pass failed: {e!r}\n")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = 2.0 * tot["FETCH_SIZE"] * 1024.0 / n_steps
+    wr = tot["WRITE_SIZE"] * 1024.0 / n_steps
+    return {"traffic": rd + wr, "read_bytes": rd, "write_bytes": wr,
+            "note": f"bytes per denoiser step, live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a "
+                    f"{n_steps}-step one-lane run of this command; FETCH_SIZE x 2 (gfx950), KB -> bytes; L2<->fabric side, "
+                    "Infinity-Cache hits included"}
 
 
 def main():
@@ -130,6 +216,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     n_gpus = world
     coll_dev = "cpu" if share_gpu else "cuda"
+    formed = {"world_size": 1, "backend": None}
+    if dist is not None:
+        # what the process group actually formed (not what the environment asked for)
+        formed = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
+        assert formed["world_size"] == world, (formed, world)
 
     import hudiff_amd
     from hudiff_amd import synthetic as S
@@ -139,7 +230,7 @@ def main():
     mode = args.mode or ("finetune" if kind == "ab" else "plain")
     sd = S.random_state_dict(kind, cfg, seed=0)
     B = args.batch
-    batch = S.synthetic_batch(kind, B, seed=2023, mode=mode, row0=rank * B)
+    batch, real = make_batch(kind, B, mode, rank * B, args.data)
     T = batch["T"].copy()
     if args.max_t > 0:
         T = np.minimum(T, args.max_t)
@@ -205,39 +296,57 @@ def main():
         executed_flops = float(B * Tmax) * flops_row_exec * args.steps     # every row is computed every step
         achieved = useful_flops / (gpu_ms * 1e-3) / 1e12
         out = {
-            "metric": "humanized sequences/sec (full T-step sample)",
+            "metric": "humanized sequences/sec (full T-step sample)" + (" on HuAb348" if (real and kind == "ab") else ""),
             "value": round(value, 4), "unit": "sequences/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("HuDiff-Ab AntiTFNet (39.8M params, L=291), HuAb348-shaped synthetic rows, "
-                                    if kind == "ab" else "HuDiff-Nb NanoAntiTFNet (17.5M params, L=152), VHH-shaped synthetic rows, ")
-                       + f"{mode} mask, batch {B}/GPU, full T-step sample (mean T {float(batch['T'].mean()):.1f}), "
-                         f"dropout {args.dropout}",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": (("HuAb348 mouse pairs" if kind == "ab" else "abnativ_select_vhh VHH") +
+                     f" ({batch['n_sequences']} sequences of the reference's evaluation CSV, IMGT-slotted by hudiff_amd.numbering into "
+                     "tests/golden/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
+            if real else "synthetic",
+            "config": {"workload": (("HuDiff-Ab AntiTFNet (39.8M params, L=291) on HuAb348, " if real else
+                                     "HuDiff-Ab AntiTFNet (39.8M params, L=291), HuAb348-shaped synthetic rows, ")
+                                    if kind == "ab" else
+                                    ("HuDiff-Nb NanoAntiTFNet (17.5M params, L=152) on abnativ_select_vhh, " if real else
+                                     "HuDiff-Nb NanoAntiTFNet (17.5M params, L=152), VHH-shaped synthetic rows, "))
+                       + f"{mode} mask, batch {B}/GPU, full T-step sample (T {int(batch['T'].min())}..{int(batch['T'].max())}, "
+                         f"mean {float(batch['T'].mean()):.1f}), dropout {args.dropout}",
                        "rows_per_gpu": B, "global_rows": n_gpus * B, "denoiser_steps_per_sample": Tmax,
-                       "parallelism": f"rows sharded x{n_gpus}, one RCCL gather of int32 tokens"},
+                       "parallelism": f"rows sharded x{n_gpus}, one RCCL gather of int32 tokens",
+                       "process_group": formed},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
                          "launch": "one denoiser step = one replay of the captured hipGraph (all kernels of a forward "
                                    "+ sampling), HIP events on the library's stream",
                          "flops_per_launch": B * flops_row, "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
                          "executed_tflops": round(executed_flops / (gpu_ms * 1e-3) / 1e12, 3),
+                         "executed_frac": round(executed_flops / (gpu_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
                          "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)},
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
         }
-        # HBM-side traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            c = tr["config"]      # measured with one lane; the bytes do not depend on how the batch is split into lanes
-            if (c["kind"], c["rows_per_gpu"], c["dropout"]) == (kind, B, args.dropout):
-                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "bytes per denoiser step, profiles/r01/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"
-        except Exception:
-            pass
+        # HBM-side traffic per launch: live PMC passes of this very command (subprocess, after the timed region), else the
+        # committed passes of the round (profiles/r02/pmc_traffic.json, stamped with the commit they were taken at)
+        if args.traffic in ("auto", "live") and n_gpus == 1 and args.max_t == 0:
+            lt = live_traffic(args, kind, mode)
+            if lt is not None:
+                out["roofline"]["traffic"] = lt["traffic"]
+                out["roofline"]["traffic_read_bytes"], out["roofline"]["traffic_write_bytes"] = lt["read_bytes"], lt["write_bytes"]
+                out["roofline"]["traffic_note"] = lt["note"]
+        if out["roofline"]["traffic"] is None and args.traffic in ("auto", "file"):
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
+                c = tr["config"]      # measured with one lane; the bytes do not depend on how the batch is split into lanes
+                if (c["kind"], c["rows_per_gpu"], c["dropout"]) == (kind, B, args.dropout):
+                    out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = ("bytes per denoiser step, profiles/r02/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE), "
+                                                       f"taken at commit {tr.get('git_head', '?')}")
+            except Exception:
+                pass
         if args.max_t > 0:
             out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(kind, cfg, sd, mode, args.cpu_rows, args.cpu_steps, float(batch["T"].mean()),
-                                               args.cpu_impl)
+                                               args.cpu_impl, args.data)
         print(json.dumps(out), flush=True)
     model.close()
     if dist is not None:

@@ -99,16 +99,18 @@ def traditional_main(args):
     """sample.py:539-576: CDR grafting only (abnumber), one 'humanization' row per mouse row and no 'mouse' rows; the log
     directory sits next to the data file."""
     data_sample = "humab" if "humab" in args.data_fpath else ("putative" if "putative" in args.data_fpath else "lab")
+    # graft first: without abnumber this raises before any directory is created
+    names, human_rows = [], []
+    for line in read_mouse_rows(args.data_fpath).itertuples():
+        human_rows.append(I.cdr_pair_grafting(line.h_seq, line.l_seq, back_mutation=bool(args.back_mutation)))
+        names.append(line.name)
     log_dir = get_new_log_dir(root=os.path.dirname(args.data_fpath), prefix=f"{data_sample}_cdr_graft_back_mutation_{args.back_mutation}")
     save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")
     get_logger("test", log_dir)
-    human_rows = []
     with open(save_fpath, "a", encoding="UTF-8") as f:
         f.write("Specific,name,hseq,lseq,\n")
-        for line in read_mouse_rows(args.data_fpath).itertuples():
-            g_h, g_l = I.cdr_pair_grafting(line.h_seq, line.l_seq, back_mutation=bool(args.back_mutation))
-            f.write(f"humanization,{line.name}human_sample,{g_h},{g_l}\n")
-            human_rows.append((g_h, g_l))
+        for name, (g_h, g_l) in zip(names, human_rows):
+            f.write(f"humanization,{name}human_sample,{g_h},{g_l}\n")
     records = []
     for i, (g_h, g_l) in enumerate(human_rows):
         records += [(args.fa_version + "human" + f"{i}", "VH", g_h), (args.fa_version + "human" + f"{i}", "VL", g_l)]

@@ -36,7 +36,8 @@ def init_process_group(backend: Optional[str] = None):
     import torch.distributed as dist
     if dist.is_initialized():
         return dist
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    # HUDIFF_DIST_BACKEND=gloo: ranks that share one GPU (tests on a 1-GPU box; RCCL refuses duplicate devices)
+    backend = backend or os.environ.get("HUDIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))

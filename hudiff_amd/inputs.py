@@ -75,7 +75,12 @@ def antibody_row(h_dict, l_dict, l_chain_type: str, finetune: bool = True, pad_r
     """-> tokens[291] (masked), region[291], chain (heavy id, light id), loc (maskable slots, ascending).
     sample.py:142-179 for one replica."""
     slots = slot_residues(h_dict, "H") + slot_residues(l_dict, "L")
-    tok = _TK.seq2idx(slots)
+    return antibody_row_from_tokens(_TK.seq2idx(slots), _TK.chain_type_idx(l_chain_type), finetune, pad_region)
+
+
+def antibody_row_from_tokens(slot_tokens, l_chain_id: int, finetune: bool = True, pad_region: int = 0):
+    """Same, from already slotted token ids [291] (21 = empty slot) and the light chain's type id."""
+    tok = np.asarray(slot_tokens).astype(np.int64)
     if not finetune:
         mask = np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0
     else:
@@ -84,7 +89,7 @@ def antibody_row(h_dict, l_dict, l_chain_type: str, finetune: bool = True, pad_r
     loc = np.arange(T.AB_LEN)[mask]
     tok = tok.copy()
     tok[mask] = _TK.idx_msk
-    chain = (_TK.chain_type_idx("H"), _TK.chain_type_idx(l_chain_type))
+    chain = (_TK.chain_type_idx("H"), int(l_chain_id))
     return tok.astype(np.int32), T.ab_region(pad_region).astype(np.int32), chain, loc
 
 
@@ -146,8 +151,12 @@ def antibody_inpaint_row(h_dict, l_dict, identity_h, identity_l, l_chain_type: s
 
 def nanobody_row(h_dict, inpaint_sample: bool = False):
     """nanosample.py:124-149 for one replica -> tokens[152], region[152], loc."""
-    slots = slot_residues(h_dict, "H")
-    tok = _TK.seq2idx(slots)
+    return nanobody_row_from_tokens(_TK.seq2idx(slot_residues(h_dict, "H")), inpaint_sample)
+
+
+def nanobody_row_from_tokens(slot_tokens, inpaint_sample: bool = False):
+    """Same, from already slotted token ids [152] (21 = empty slot)."""
+    tok = np.asarray(slot_tokens).astype(np.int64)
     table = np.array(T.INPAINT_HEAVY_CDR_INDEX if inpaint_sample else T.HEAVY_CDR_INDEX)
     mask = (table == 0) & (tok != _TK.idx_pad)
     loc = np.arange(T.H_LEN)[mask]

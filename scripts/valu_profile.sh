@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/valu
 mkdir -p $OUT
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d $OUT/p -o p --output-format csv -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --max-t 3 --no-cpu-baseline --lanes 1 --no-graph "$@" > $OUT/run.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --max-t 3 --no-cpu-baseline --traffic off --lanes 1 --no-graph "$@" > $OUT/run.log 2>&1
 tail -1 $OUT/run.log | cut -c1-200
 python3 - <<PY
 import csv, glob, collections, re

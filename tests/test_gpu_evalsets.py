@@ -1,0 +1,208 @@
+"""BASELINE.json's configurations on the HIP path with the REAL rows of the reference's evaluation sets
+(tests/golden/real_rows.npz = HuAb348 / Humab25 / abnativ_select_vhh slotted by scripts/make_real_rows.py).
+
+configs[0]  sample.py on Humab25 parental_mouse.csv, --batch_size 1                 -> test_humab25_cli_batch_1
+configs[1]  HuDiff-Ab on HuAb348, 256 rows per GPU                                   -> test_huab348_full_batch
+configs[3]  nanosample.py --model pretrain --inpaint_sample False, 256 VHH rows      -> test_vhh_full_batch[plain]
+configs[4]  --model finetune_vh --inpaint_sample True (per-GPU share: 256 rows)      -> test_vhh_full_batch[inpaint]
+configs[2] / [4] multi-GPU halves: two ranks driving real HIP handles on the one GPU -> test_two_ranks_share_the_gpu
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hudiff_amd
+    if hudiff_amd.device_count() < 1:
+        pytest.fail("no MI355X visible: GPU tests must run on the GPU box (there is no CPU fallback)")
+    return hudiff_amd
+
+
+def _production_ckpt(path, kind, seed):
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    sd = {k: torch.from_numpy(v) for k, v in S.random_state_dict(kind, cfg, seed=seed).items()}
+    if kind == "ab":
+        torch.save({"fineconfig": ck.EasyDict({}), "pretrain_config": ck.EasyDict({"name": "trans_oadm", "model": cfg}), "model": sd}, path)
+    else:
+        torch.save({"config": ck.EasyDict({"name": "nano", "model": cfg}), "model": sd}, path)
+
+
+def _fixed_runs(parent_tokens, loc, lo, hi):
+    """Maximal runs (>= 4 residues) of slots in [lo, hi) that are neither sampled nor empty, as strings."""
+    from hudiff_amd.inputs import _TK
+    sampled = set(int(x) for x in loc)
+    runs, cur = [], ""
+    for s in range(lo, hi):
+        if s in sampled or parent_tokens[s] == 21:
+            if s in sampled and len(cur) >= 4:
+                runs.append(cur)
+            if s in sampled:
+                cur = ""
+            continue
+        cur += _TK.idx2seq(np.array([parent_tokens[s]]))
+    if len(cur) >= 4:
+        runs.append(cur)
+    return runs
+
+
+def test_humab25_cli_batch_1(hip, tmp_path):
+    """configs[0]: the drop-in CLI on the 25 Humab25 parental pairs at the reference's default --batch_size 1, production
+    architecture, raw sequences through the built-in slotter.  One humanization row per mouse row, in file order; the
+    Kabat CDRs (everything the finetune mask does not visit) come out untouched."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import inputs as I
+    from hudiff_amd.cli import sample as cli
+    from hudiff_amd.numbering import number_sequence_builtin
+    z = E.load_rows()
+    seqs = E.sequences("humab25")
+    names = [str(n) for n in z["humab25_names"]]
+    assert len(seqs) == 25
+    ckdir = tmp_path / "run" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    _production_ckpt(ckdir / "hudiffab.pt", "ab", seed=1)
+    csv = tmp_path / "humab25_parental_mouse.csv"
+    with open(csv, "w") as f:
+        f.write(",type,name,h_seq,l_seq\n")
+        for i, (name, (h, l)) in enumerate(zip(names, seqs)):
+            f.write(f"{i},mouse,{name},{h},{l}\n")
+    out = cli.main(["--ckpt", str(ckdir / "hudiffab.pt"), "--data_fpath", str(csv), "--numbering", "builtin",
+                    "--batch_size", "1", "--seed", "2023"])
+    assert "_humab_" in os.path.basename(os.path.dirname(out))
+    lines = open(out).read().splitlines()
+    assert lines[0] == "Specific,name,hseq,lseq," and len(lines) == 1 + 2 * 25
+    n_changed = 0
+    for i, (name, (h, l)) in enumerate(zip(names, seqs)):
+        m, s = lines[1 + 2 * i].split(","), lines[2 + 2 * i].split(",")
+        assert m == ["mouse", name, h, l] and s[:2] == ["humanization", name + "human_sample"]
+        # the slotter on this box reproduces the fixture (same numbering code in the build container and here)
+        hd, ld = number_sequence_builtin(h)[0], number_sequence_builtin(l)[0]
+        parent = np.array(I._TK.seq2idx(I.slot_residues(hd, "H") + I.slot_residues(ld, "L")))
+        assert np.array_equal(parent, z["humab25_tokens"][i].astype(parent.dtype))
+        _, _, _, loc = I.antibody_row_from_tokens(parent, int(z["humab25_lchain"][i]), finetune=True)
+        for chain_seq, lo, hi in ((s[2], 0, 152), (s[3], 152, 291)):
+            assert set(chain_seq) <= set("ACDEFGHIKLMNPQRSTVWYX")
+            pos = 0
+            for run in _fixed_runs(parent, loc, lo, hi):
+                pos = chain_seq.index(run, pos) + len(run)               # CDRs / unvisited framework preserved, in order
+        n_changed += (s[2], s[3]) != (h, l)
+    assert n_changed == 25
+    fa = open(os.path.join(os.path.dirname(out), "sample_identity.fa")).read().splitlines()
+    assert len(fa) == 4 * 25 and fa[0] == ">v007human0 VH"
+
+
+def test_huab348_full_batch(hip):
+    """configs[1]: 256 HuAb348 rows (ragged T 141..154), production width, one complete sample; size-independent
+    properties: every visited slot filled with an id in [0, 21], nothing else touched; rows independent of the batch
+    (first 24 rows == a 24-row run with the same global ids); replicas of one antibody differ (distinct noise)."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG)
+    m = hip.AntiTFNet(**cfg)
+    m.load_state_dict(S.random_state_dict("ab", cfg, seed=0))
+    try:
+        B = 256
+        batch = E.eval_batch("huab348", B, row0=256)            # rows 256..511: pairs 256..347 then 0..163 (replica 1)
+        assert batch["T"].min() >= 130 and batch["T"].max() <= 157 and len(set(batch["T"].tolist())) > 3
+        out = m.sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], batch["T"], seed=9, row0=256)
+        assert not (out == 22).any()
+        changed = out != batch["tokens"]
+        assert (changed.sum(1) == batch["T"]).all() and ((out[changed] >= 0) & (out[changed] <= 21)).all()
+        for b in range(0, B, 41):
+            assert set(np.nonzero(changed[b])[0]) == set(batch["order"][b, :batch["T"][b]].tolist())
+        ch = np.concatenate([batch["chain"][:24], batch["chain"][B:B + 24]])
+        small = m.sample(batch["tokens"][:24], batch["region"][:24], ch, batch["order"][:24, :int(batch["T"][:24].max())],
+                         batch["T"][:24], seed=9, row0=256)
+        assert np.array_equal(out[:24], small)
+        # the same antibody as two replicas (global rows g and g + 348) must not draw the same noise
+        b2 = E.eval_batch("huab348", 8, row0=256 + 348)
+        assert np.array_equal(b2["truth"], batch["truth"][:8])
+        out2 = m.sample(b2["tokens"], b2["region"], b2["chain"], b2["order"], b2["T"], seed=9, row0=256 + 348)
+        assert (out2 != out[:8]).any()
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "inpaint"])
+def test_vhh_full_batch(hip, mode):
+    """configs[3] / configs[4] per-GPU workload: 256 abnativ_select_vhh rows, HEAVY_CDR_INDEX (T <= 93) or
+    INPAINT_HEAVY_CDR_INDEX (T <= 87) mask, production NanoAntiTFNet, one complete sample."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import synthetic as S
+    from hudiff_amd import tables as T
+    cfg = dict(S.NB_CONFIG)
+    m = hip.NanoAntiTFNet(**cfg)
+    m.load_state_dict(S.random_state_dict("nb", cfg, seed=2))
+    try:
+        B = 256
+        batch = E.eval_batch("vhh", B, mode=mode, row0=0)
+        table = np.array(T.INPAINT_HEAVY_CDR_INDEX if mode == "inpaint" else T.HEAVY_CDR_INDEX)
+        assert batch["T"].max() <= (87 if mode == "inpaint" else 93)
+        out = m.sample(batch["tokens"], batch["region"], None, batch["order"], batch["T"], seed=5, row0=0)
+        assert not (out == 22).any()
+        changed = out != batch["tokens"]
+        assert (changed.sum(1) == batch["T"]).all() and not changed[:, table != 0].any()        # CDRs / Vernier anchors kept
+        assert ((out[changed] >= 0) & (out[changed] <= 21)).all()
+        small = m.sample(batch["tokens"][:32], batch["region"][:32], None, batch["order"][:32], batch["T"][:32], seed=5, row0=0)
+        assert np.array_equal(out[:32], small)
+        if mode == "inpaint":                                    # the two masks differ exactly at the inpaint anchors
+            plain = E.eval_batch("vhh", 4, mode="plain")
+            assert (plain["T"] > batch["T"][:4]).all()
+    finally:
+        m.close()
+
+
+def _torchrun(nproc, args, env_extra, cwd, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_two_ranks_share_the_gpu(hip, tmp_path):
+    """N > 1 with real HIP handles: two ranks, both on device 0 (gloo gather -- RCCL refuses two ranks on
+    one device), drive the drop-in CLI over 12 Humab25 pairs x 3 replicas; the CSV must equal the single-process CSV
+    byte for byte (rows sharded by global id, noise keyed by global row).  Then bench.py's own N = 2 control flow."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd.cli import sample as cli
+    seqs = E.sequences("humab25")[:12]
+    csv = tmp_path / "pairs.csv"
+    with open(csv, "w") as f:
+        f.write("type,name,h_seq,l_seq\n")
+        for i, (h, l) in enumerate(seqs):
+            f.write(f"mouse,p{i},{h},{l}\n")
+    outs = []
+    for tag, nproc in (("one", 1), ("two", 2)):
+        ckdir = tmp_path / tag / "checkpoints"
+        ckdir.mkdir(parents=True)
+        _production_ckpt(ckdir / "hudiffab.pt", "ab", seed=3)
+        argv = ["--ckpt", str(ckdir / "hudiffab.pt"), "--data_fpath", str(csv), "--numbering", "builtin", "--batch_size", "3",
+                "--seed", "7", "--device", "0", "--device_batch", "16", "--similarity_search", ""]
+        if nproc == 1:
+            outs.append(cli.main(argv))
+        else:
+            r = _torchrun(2, ["-m", "hudiff_amd.cli.sample"] + argv, {"HUDIFF_DIST_BACKEND": "gloo"}, str(tmp_path), 29611)
+            assert r.returncode == 0, r.stderr[-3000:]
+            logs = [d for d in os.listdir(tmp_path / tag) if d != "checkpoints"]
+            assert len(logs) == 1                                      # only rank 0 writes
+            outs.append(str(tmp_path / tag / logs[0] / "sample_humanization_result.csv"))
+    one, two = open(outs[0]).read(), open(outs[1]).read()
+    assert one == two and one.count("humanization,") == 12
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "24", "--max-t", "2",
+                      "--no-cpu-baseline", "--traffic", "off"], {"HUDIFF_BENCH_SHARE_GPU": "1"}, str(tmp_path), 29612)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["process_group"]["world_size"] == 2 and line["config"]["global_rows"] == 48
+    assert line["all_tokens_valid"]

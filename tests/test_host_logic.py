@@ -262,6 +262,28 @@ def test_traditional_method_layout(tmp_path, monkeypatch):
     assert fa[0] == ">v007human0 VH" and fa[1] == "G" + H_SEQ and len(fa) == 8
 
 
+def test_evalset_fixture_rows():
+    """tests/golden/real_rows.npz (scripts/make_real_rows.py): the reference's evaluation rows as slot tokens."""
+    from hudiff_amd import evalsets as E
+    z = E.load_rows()
+    assert z["huab348_tokens"].shape == (348, 291) and z["humab25_tokens"].shape == (25, 291) and z["vhh_tokens"].shape == (300, 152)
+    assert set(np.unique(z["huab348_lchain"])) <= {1, 2} and ((z["huab348_tokens"] >= 0) & (z["huab348_tokens"] <= 21)).all()
+    b = E.eval_batch("huab348", 400, row0=0)
+    assert (b["T"].min(), b["T"].max()) == (141, 154) and abs(float(b["T"][:348].mean()) - 152.86) < 0.01
+    assert np.array_equal(b["truth"][348:400], b["truth"][:52]) and not np.array_equal(b["order"][348], b["order"][0])
+    for r in (0, 17, 399):                                   # masks follow the reference's finetune rule (tests/test_input_prep_golden.py)
+        maskable = np.array(T.HEAVY_CDR_KABAT_NO_VERNIER + T.LIGHT_CDR_KABAT_NO_VERNIER) == 0
+        want = maskable & (b["truth"][r] != 21)
+        assert np.array_equal(b["tokens"][r] == 22, want) and sorted(b["order"][r, :b["T"][r]]) == np.nonzero(want)[0].tolist()
+    # sharding: rows of a later block are the same rows (global ids key everything)
+    c = E.eval_batch("huab348", 16, row0=384)
+    assert np.array_equal(c["tokens"], b["tokens"][384:400]) and np.array_equal(c["order"][:, :c["T"].max()], b["order"][384:400, :c["T"].max()])
+    v = E.eval_batch("vhh", 300, mode="inpaint")
+    assert v["T"].max() <= 87 and v["chain"] is None
+    h, l = E.sequences("humab25")[0]
+    assert h.startswith("EVKLQQSGPGLV") and l.endswith("GGGTKLEIK")
+
+
 def test_fasta_writers(tmp_path):
     from hudiff_amd.cli.common import write_fasta_2line, write_fasta_wrapped
     p = tmp_path / "a.fa"
