@@ -55,14 +55,19 @@ struct HostTensor {
     std::vector<float> data;
 };
 
+// A weight matrix in the split-precision form gemm_x3_k consumes (HUDIFF_X3=1): pre-tiled (hi, lo) fp16 planes,
+// per-segment stride in halfs, and the power-of-two factor that undoes weight and activation scaling.
+struct X3W { const uint16_t* w = nullptr; long seg_stride = 0; float acc_scale = 1.f; long ntile_stride = 0; };
 struct ByteNetW {   // one ByteNet block, both segments packed back to back
     const float *ln1_g, *ln1_b, *w1, *b1, *ln2_g, *ln2_b, *wc, *bc, *ln3_g, *ln3_b, *w3, *b3;
     int dil;
+    X3W wcx;
 };
-struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; };
+struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; X3W wqkvx, wox; };
 struct AttBlockW {
     AttLayerW a1, a2;
     const float *n1_g, *n1_b, *n2_g, *n2_b, *wf1, *bf1, *wf2, *bf2;     // a2.wqkv / bqkv and wf1 / bf1 hold norm_hl1 / norm_hl2 folded in
+    X3W wf1x, wf2x;
 };
 
 struct Workspace {
@@ -102,6 +107,8 @@ struct HdModel {
     float p_enc = 0.f, p_conv = 0.f;
     // device weights
     float* blob = nullptr;
+    uint16_t* blobx = nullptr;        // split-precision copies of the GEMM weights (HUDIFF_X3=1 at hd_finalize)
+    bool x3 = false;
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
     std::vector<AttBlockW> att;
@@ -261,6 +268,7 @@ extern "C" void hd_destroy(HdModel* m) {
         if (ln.stream) hipStreamDestroy(ln.stream);
     }
     if (m->blob) hipFree(m->blob);
+    if (m->blobx) hipFree(m->blobx);
     if (m->side_vec) hipFree(m->side_vec);
     if (m->emb_stats) hipFree(m->emb_stats);
     if (m->qnoise) hipFree(m->qnoise);
@@ -352,7 +360,9 @@ struct Loader {
 
 static void append(std::vector<float>& a, const std::vector<float>& b) { a.insert(a.end(), b.begin(), b.end()); }
 
-struct ByteNetOff { size_t ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3; };
+struct X3Off;
+struct X3Packer;
+struct ByteNetOff { size_t ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3; std::vector<float> wc_copy; };
 
 static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::string>& prefixes, int din, int dh, int ks) {
     std::vector<float> ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3;
@@ -368,6 +378,7 @@ static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::st
     o.ln1_g = pk.add(ln1_g); o.ln1_b = pk.add(ln1_b); o.w1 = pk.add(w1); o.b1 = pk.add(b1);
     o.ln2_g = pk.add(ln2_g); o.ln2_b = pk.add(ln2_b); o.wc = pk.add(wc); o.bc = pk.add(bc);
     o.ln3_g = pk.add(ln3_g); o.ln3_b = pk.add(ln3_b); o.w3 = pk.add(w3); o.b3 = pk.add(b3);
+    o.wc_copy = wc;          // kept for the split-precision copy (hd_finalize)
     return o;
 }
 
@@ -389,8 +400,52 @@ static void fold_layernorm(std::vector<float>& w, std::vector<float>& b, const s
     for (int n = 0; n < N; ++n) b[n] = (float)((double)b[n] + t[n]);
 }
 
-struct AttLayerOff { size_t wqkv, bqkv, wo, bo; };
-static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, const std::string& p, int D, int A,
+// ---- split-precision weight packing (gemm_x3_k) ----------------------------------------------------
+// w: nseg matrices [Ktot, N] (row-major, back to back).  Output per segment: tiles [N/128][Ktot/32] of hi[128 n][32 k] then
+// lo[128][32] fp16, values scaled by 2^shift with shift chosen so that the largest |w| lands in [2^13, 2^14): the lo parts
+// (2^-11 of the value) then stay normal fp16 numbers for everything within 2^-12 of the largest weight.
+struct X3Off { size_t off = 0; long seg_stride = 0; float acc_scale = 1.f; long ntile_stride = 0; bool ok = false; };
+struct X3Packer {
+    std::vector<uint16_t> buf;
+    static uint16_t h16(float x) { _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
+    static float f16(float x) { return (float)(_Float16)x; }
+    X3Off add(const std::vector<float>& w, int nseg, int Ktot, int N) {
+        X3Off o;
+        if (Ktot % X3_BK || N % X3_BN || w.size() != (size_t)nseg * Ktot * N) return o;
+        float mx = 0.f;
+        for (float v : w) mx = fmaxf(mx, fabsf(v));
+        int e = 0;
+        if (mx > 0.f) frexpf(mx, &e);                   // mx = f * 2^e, f in [0.5, 1)
+        const int shift = 14 - e;                       // mx * 2^shift in [2^13, 2^14)
+        const float sc = ldexpf(1.f, shift);
+        o.off = (buf.size() + 63) / 64 * 64;
+        const int nt = N / X3_BN, kt = Ktot / X3_BK;
+        o.seg_stride = (long)nt * kt * X3_TILE_HALFS;
+        o.ntile_stride = (long)kt * X3_TILE_HALFS;
+        o.acc_scale = ldexpf(1.f, -shift) / X3_A_SCALE;
+        buf.resize(o.off + (size_t)nseg * o.seg_stride);
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            const float* ws = w.data() + (size_t)sgi * Ktot * N;
+            uint16_t* dst = buf.data() + o.off + (size_t)sgi * o.seg_stride;
+            for (int a = 0; a < nt; ++a)
+                for (int b = 0; b < kt; ++b) {
+                    uint16_t* t = dst + ((size_t)a * kt + b) * X3_TILE_HALFS;
+                    for (int n = 0; n < X3_BN; ++n)
+                        for (int k = 0; k < X3_BK; ++k) {
+                            const float v = ws[(size_t)(b * X3_BK + k) * N + a * X3_BN + n] * sc;
+                            const float hi = f16(v);
+                            t[n * X3_BK + k] = h16(hi);
+                            t[X3_BN * X3_BK + n * X3_BK + k] = h16(v - hi);
+                        }
+                }
+        }
+        o.ok = true;
+        return o;
+    }
+};
+
+struct AttLayerOff { size_t wqkv, bqkv, wo, bo; X3Off wqkvx, wox; };
+static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, X3Packer* xp, const std::string& p, int D, int A,
                                  const std::vector<float>* ln_g = nullptr, const std::vector<float>* ln_b = nullptr) {
     // fused [D, 3A] = [query | key | value]
     auto q = ld.lin_t(p + "query.weight", A, D), k = ld.lin_t(p + "key.weight", A, D), v = ld.lin_t(p + "value.weight", A, D);
@@ -405,7 +460,9 @@ static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, const std::string& p, i
     AttLayerOff o;
     if (ln_g) fold_layernorm(w, b, *ln_g, *ln_b, D, 3 * A);
     o.wqkv = pk.add(w); o.bqkv = pk.add(b);
-    o.wo = pk.add(ld.lin_t(p + "out_put.weight", D, A)); o.bo = pk.add(ld.vec(p + "out_put.bias", D));
+    const std::vector<float> wo = ld.lin_t(p + "out_put.weight", D, A);
+    o.wo = pk.add(wo); o.bo = pk.add(ld.vec(p + "out_put.bias", D));
+    if (xp) { o.wqkvx = xp->add(w, 1, D, 3 * A); o.wox = xp->add(wo, 1, A, D); }
     return o;
 }
 
@@ -417,6 +474,9 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, A = m->A, Fd = m->Fd, L = m->L, ks = c.kernel_size;
     Loader ld{m};
     Packer pk;
+    X3Packer xpk;
+    { const char* e = getenv("HUDIFF_X3"); m->x3 = e && atoi(e) != 0; }
+    X3Packer* xp = m->x3 ? &xpk : nullptr;
     const bool ab = c.kind == HD_KIND_ANTIBODY;
     const std::vector<std::string> segn = ab ? std::vector<std::string>{"h_layers", "l_layers"} : std::vector<std::string>{"layers"};
     const std::string convp = ab ? "dual_conv_block." : "nano_conv_block.";
@@ -436,7 +496,10 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         for (auto& s : segn) pf.push_back(convp + s + "." + std::to_string(n) + ".");
         conv_off.push_back(pack_bytenet(ld, pk, pf, D, Dh, ks));
     }
-    struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2; };
+    std::vector<X3Off> enc_x, conv_x;
+    for (auto& o : enc_off) { enc_x.push_back(xp ? xp->add(o.wc_copy, m->nseg, ks * dh, dh) : X3Off()); o.wc_copy.clear(); o.wc_copy.shrink_to_fit(); }
+    for (auto& o : conv_off) { conv_x.push_back(xp ? xp->add(o.wc_copy, m->nseg, ks * Dh, Dh) : X3Off()); o.wc_copy.clear(); o.wc_copy.shrink_to_fit(); }
+    struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2; X3Off wf1x, wf2x; };
     std::vector<AttOff> att_off;
     for (int n = 0; n < c.cs_layers; ++n) {
         std::string p = "self_at.layers." + std::to_string(n) + ".";
@@ -444,16 +507,21 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         // norm_hl1 is folded into the second attention's Q|K|V projection, norm_hl2 into the first FF layer
         const std::vector<float> n1g = ld.vec(p + "norm_hl1.weight", D), n1b = ld.vec(p + "norm_hl1.bias", D);
         const std::vector<float> n2g = ld.vec(p + "norm_hl2.weight", D), n2b = ld.vec(p + "norm_hl2.bias", D);
-        o.a1 = pack_attlayer(ld, pk, p + "attn_hl.", D, A);
-        o.a2 = pack_attlayer(ld, pk, p + "attn_hl_c.", D, A, &n1g, &n1b);
+        o.a1 = pack_attlayer(ld, pk, xp, p + "attn_hl.", D, A);
+        o.a2 = pack_attlayer(ld, pk, xp, p + "attn_hl_c.", D, A, &n1g, &n1b);
         o.n1_g = pk.add(n1g); o.n1_b = pk.add(n1b);
         o.n2_g = pk.add(n2g); o.n2_b = pk.add(n2b);
         {
             std::vector<float> wf1 = ld.lin_t(p + "ff_hl.0.weight", Fd, D), bf1 = ld.vec(p + "ff_hl.0.bias", Fd);
             fold_layernorm(wf1, bf1, n2g, n2b, D, Fd);
             o.wf1 = pk.add(wf1); o.bf1 = pk.add(bf1);
+            if (xp) o.wf1x = xp->add(wf1, 1, D, Fd);
         }
-        o.wf2 = pk.add(ld.lin_t(p + "ff_hl.2.weight", D, Fd)); o.bf2 = pk.add(ld.vec(p + "ff_hl.2.bias", D));
+        {
+            const std::vector<float> wf2 = ld.lin_t(p + "ff_hl.2.weight", D, Fd);
+            o.wf2 = pk.add(wf2); o.bf2 = pk.add(ld.vec(p + "ff_hl.2.bias", D));
+            if (xp) o.wf2x = xp->add(wf2, 1, Fd, D);
+        }
         att_off.push_back(o);
     }
     // region / position branch
@@ -518,18 +586,28 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     HIP_TRY(hipMalloc(&m->blob, pk.buf.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(m->blob, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* B0 = m->blob;
+    if (m->x3 && !xpk.buf.empty()) {
+        HIP_TRY(hipMalloc(&m->blobx, xpk.buf.size() * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpy(m->blobx, xpk.buf.data(), xpk.buf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    auto mkx = [&](const X3Off& o) {
+        X3W x;
+        if (o.ok && m->blobx) { x.w = m->blobx + o.off; x.seg_stride = o.seg_stride; x.acc_scale = o.acc_scale; x.ntile_stride = o.ntile_stride; }
+        return x;
+    };
     m->emb = B0 + o_emb;
     auto mk = [&](const ByteNetOff& o, int n) {
         ByteNetW w{B0 + o.ln1_g, B0 + o.ln1_b, B0 + o.w1, B0 + o.b1, B0 + o.ln2_g, B0 + o.ln2_b, B0 + o.wc, B0 + o.bc,
                    B0 + o.ln3_g, B0 + o.ln3_b, B0 + o.w3, B0 + o.b3, dilation_of(c, n)};
         return w;
     };
-    for (int n = 0; n < c.n_encoder_layers; ++n) m->enc.push_back(mk(enc_off[n], n));
-    for (int n = 0; n < c.dual_layers; ++n) m->conv.push_back(mk(conv_off[n], n));
+    for (int n = 0; n < c.n_encoder_layers; ++n) { m->enc.push_back(mk(enc_off[n], n)); m->enc.back().wcx = mkx(enc_x[n]); }
+    for (int n = 0; n < c.dual_layers; ++n) { m->conv.push_back(mk(conv_off[n], n)); m->conv.back().wcx = mkx(conv_x[n]); }
     for (auto& o : att_off) {
         AttBlockW w;
-        w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo};
-        w.a2 = {B0 + o.a2.wqkv, B0 + o.a2.bqkv, B0 + o.a2.wo, B0 + o.a2.bo};
+        w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo, mkx(o.a1.wqkvx), mkx(o.a1.wox)};
+        w.a2 = {B0 + o.a2.wqkv, B0 + o.a2.bqkv, B0 + o.a2.wo, B0 + o.a2.bo, mkx(o.a2.wqkvx), mkx(o.a2.wox)};
+        w.wf1x = mkx(o.wf1x); w.wf2x = mkx(o.wf2x);
         w.n1_g = B0 + o.n1_g; w.n1_b = B0 + o.n1_b; w.n2_g = B0 + o.n2_g; w.n2_b = B0 + o.n2_b;
         w.wf1 = B0 + o.wf1; w.bf1 = B0 + o.bf1; w.wf2 = B0 + o.wf2; w.bf2 = B0 + o.bf2;
         m->att.push_back(w);
@@ -614,6 +692,11 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     return p;
 }
 
+static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
+    if (!x.w) return;
+    p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
+}
+
 // k-tile depth of the GEMM K loop: 16 by default, HUDIFF_GEMM_BK=32 selects the 32-deep variant (tuning aid)
 static int gemm_bk() {
     static int bk = [] { const char* e = getenv("HUDIFF_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
@@ -682,6 +765,22 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     const bool fast_ok = p.Kc % 16 == 0 && rows * lda * 4 < (1L << 31) && (long)p.taps * p.Kc * ldw * 4 < (1L << 31);
     p.a_bytes = fast_ok ? (uint32_t)(rows * lda * 4) : 0;
     p.w_bytes = fast_ok ? (uint32_t)((long)p.taps * p.Kc * ldw * 4) : 0;
+    // split-precision variant: big launches without an A prologue whose shape the 128 x 128 x 32 tiles cover exactly
+    const bool no_pro = p.ln_fold || (!p.stats && !p.spart);
+    if (p.Wx && big && fast_ok && no_pro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
+        Segs run = p.sg;
+        if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
+        GemmP q = p;
+        q.sg = run;
+        const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
+        q.tiles0 = (rows0 + X3_BM - 1) / X3_BM;
+        q.tiles_m = q.tiles0 + (rows1 + X3_BM - 1) / X3_BM;
+        q.tiles_n = q.N / X3_BN;
+        dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
+        if (conv) hipLaunchKernelGGL((gemm_x3_k<true>), grid, blk, 0, st, q);
+        else hipLaunchKernelGGL((gemm_x3_k<false>), grid, blk, 0, st, q);
+    } else {
+    p.Wx = nullptr;
     if (big && fast_ok && tiles128 < small_tiles) {
         // few 128-row tiles (narrow outputs of the token encoder): 64-row tiles balance the 256 CUs better
         launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
@@ -691,6 +790,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
+    }
     }
     if (!p.part) return;
     ws.part_last = p.part; ws.part_last_pw = pw; ws.part_next ^= 1;
@@ -748,6 +848,7 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
+    use_x3(p, w.wcx);
     launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
@@ -769,6 +870,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
     if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
+    use_x3(p, w.wqkvx);
     launch_gemm(m, p, false, false);
     const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
@@ -779,6 +881,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p = base_gemm(m, sg);
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
+    use_x3(p, w.wox);
     launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
@@ -819,6 +922,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.N = via_rows ? A : 2 * A; p.Kc = D; p.ln_fold = 1;
     use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
     const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
+    use_x3(p, w.a2.wqkvx, A / X3_BN);           // column slice [A, ...) of the fused matrix = n tiles from A / 128 on
     launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -889,10 +993,12 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
         p.ln_fold = 1; p.epi_act = ACT_RELU;       // LN2 folded into wf1 / bf1
         use_partials(m, p);         // statistics of `at`: partials left by the second attention's out-projection
+        use_x3(p, w.wf1x);
         launch_gemm(m, p, false, false);
         p = base_gemm(m, sg);
         p.A = ws.F1; p.lda = m->Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Y; p.ldc = D; p.N = D; p.Kc = m->Fd;
         p.resid = ws.Y; p.ldr = D;
+        use_x3(p, w.wf2x);
         launch_gemm(m, p, false, false);
     }
     HIP_TRY(hipGetLastError());

@@ -135,6 +135,9 @@ struct GemmP {
     // operands
     const float* A; int lda;          // [rows, Kc] activation (segment-major rows)
     const float* W;                   // [taps*Kc, N] row-major, per segment at + seg * w_stride
+    // split-precision variant (gemm_x3_k): W as pre-tiled (hi, lo) fp16 planes scaled by a power of two, per segment at
+    // + seg * wx_stride halfs; acc_scale = 2^-(weight shift + activation shift) undoes the scaling in the epilogue
+    const uint16_t* Wx; long wx_stride; float acc_scale;
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
     float* C; int ldc;                // [rows, N]
     int N, Kc, taps, dil;             // K = taps * Kc
@@ -269,6 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const bool valid = lrow < seg_rows && col_ok;
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
+                if (p.Wx) v *= p.acc_scale;                               // split-precision operands were scaled by powers of two
                 if (p.ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
@@ -332,6 +336,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
         }
     }
+}
+
+// (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
+__device__ __forceinline__ float2 gemm_row_stat(const GemmP& p, long grow) {
+    if (!p.spart) return p.stats[grow];
+    const int Kc = p.Kc;
+    const int P = (Kc + p.spw - 1) / p.spw;
+    float mean = 0.f;
+    for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + grow].x * (float)min(p.spw, Kc - s * p.spw);
+    mean /= (float)Kc;
+    float m2 = 0.f;
+    for (int s = 0; s < P; ++s) {
+        const float2 pr = p.spart[(long)s * p.spart_rows + grow];
+        const float d = pr.x - mean;
+        m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
+    }
+    return make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
 }
 
 // ABLATE (probe builds only, scripts/gemm_probe.hip): 1 = no global loads inside the K loop,
@@ -400,21 +421,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
 
-    // (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
-    auto row_stat = [&](long grow) -> float2 {
-        if (!p.spart) return p.stats[grow];
-        const int P = (Kc + p.spw - 1) / p.spw;
-        float mean = 0.f;
-        for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + grow].x * (float)min(p.spw, Kc - s * p.spw);
-        mean /= (float)Kc;
-        float m2 = 0.f;
-        for (int s = 0; s < P; ++s) {
-            const float2 pr = p.spart[(long)s * p.spart_rows + grow];
-            const float d = pr.x - mean;
-            m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
-        }
-        return make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
-    };
+    auto row_stat = [&](long grow) -> float2 { return gemm_row_stat(p, grow); };
     // per-thread staging coordinates (fixed over the K loop)
     const int a_kq = tid % KQ;                        // k quad within the k tile (same for every A row of a thread)
     int a_r[AIT], a_pos[AIT];
@@ -654,6 +661,183 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     }
     if (NBUF == 2) __syncthreads();
 
+    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Split-precision GEMM (prototype behind HUDIFF_X3=1; the fp32 gemm_k stays the reference product path).
+//
+// gfx950 multiplies fp32 operands on the matrix cores at 1/16 of the fp16 rate and has no TF32-like mode.  Here every
+// fp32 operand is written as hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significand bits; x - hi is exact in
+// fp32) and   a w  ~=  a_hi w_hi + a_hi w_lo + a_lo w_hi   runs as three v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+// every fp16 x fp16 product is exact in fp32, the dropped a_lo w_lo term and the two roundings of the lo parts are each
+// <= 2^-22 relative -- the size of the rounding an fp32 accumulation makes at EVERY one of its K steps.  Three
+// 32-cycle MFMAs cover K = 16 for which the fp32 form needs eight 64-cycle ones.
+//   Weights are split once at hd_finalize (power-of-two scaled so that the lo parts stay normal fp16 numbers, laid out
+//   as the 128 x 32 tiles the blocks consume: plain 16-byte copies into LDS); activations are split while they are
+//   staged (scaled by 2^4: |x| up to 4094 representable, lo parts exact to 2^-29 absolute); the epilogue multiplies the
+//   accumulators by GemmP::acc_scale and is otherwise the fp32 kernel's own (bias, activation, residual, dropout,
+//   addend, LayerNorm partials, folded LayerNorm).
+// Shapes: Kc % 32 == 0, N % 128 == 0, no A prologue (LayerNorm folded or applied in place), operands < 2 GiB.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32;
+constexpr int X3_LDK = X3_BK + 8;                  // LDS row stride in halfs (80 B: 16-B aligned, conflict-free ds_read_b128)
+constexpr int X3_PLANE = X3_BM * X3_LDK;           // halfs per (128 x 32) plane in LDS
+constexpr int X3_TILE_HALFS = 2 * X3_BN * X3_BK;   // one pre-tiled weight tile in global memory: hi[128][32] then lo[128][32]
+constexpr float X3_A_SCALE = 16.0f;                // activations are multiplied by 2^4 before the split
+
+template <bool CONV>
+__global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
+    constexpr int BM = X3_BM, BN = X3_BN, BK = X3_BK, WM = 2, WN = 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int ES = WTN + 4;
+    constexpr int EPI_FLOATS = 4 * 32 * ES, PART_FLOATS = 4 * WTM * 2;
+    constexpr int LOOP_FLOATS = 4 * X3_PLANE / 2;
+    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
+    constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+    _Float16* Al = Ah + X3_PLANE;
+    _Float16* Wh = Al + X3_PLANE;
+    _Float16* Wl = Wh + X3_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bx, by, seg = 0;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
+        by = slot % p.tiles_n;
+        bx = (slot / p.tiles_n) * 8 + xcd;
+        if (bx >= p.tiles_m) return;
+    }
+    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+    const int Lc = p.sg.len[seg];
+    const int seg_rows = p.sg.B * Lc;
+    const int rbase = p.sg.base[seg];
+    const int m0 = bx * BM, n0 = by * BN;
+    const int Kc = p.Kc;
+    const int nkt_tap = Kc / BK;
+    const int nkt = nkt_tap * p.taps;
+    const int half = (p.taps - 1) / 2;
+    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * nkt * X3_TILE_HALFS;
+
+    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
+        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += 256) {
+            const int lrow = m0 + r;
+            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+        }
+    }
+    // A staging: 128 rows x 8 float4 per k tile; thread -> k quad tid % 8, rows tid / 8 + 32 i
+    constexpr uint32_t BUF_OOB = 0x80000000u;
+    const int a_kq = tid & 7;
+    int a_pos[4];
+    long a_row[4];
+    bool a_ok[4];
+    uint32_t t_boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lrow = m0 + (tid >> 3) + 32 * i;
+        a_ok[i] = lrow < seg_rows;
+        a_pos[i] = CONV ? (lrow % Lc) : 0;
+        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
+        t_boff[i] = a_ok[i] ? (uint32_t)((a_row[i] * p.lda + 4 * a_kq) * 4) : BUF_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_TILE_HALFS * 2, 0x00020000);
+    f32x4 ra[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rw[4];
+    auto fetch = [&](int kt) {
+        const int tap = CONV ? kt / nkt_tap : 0;
+        const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
+        if (CONV && kk0 == 0) {                        // first k tile of a tap: row shift + zero padding at the chain ends
+            const int shift = (tap - half) * p.dil;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sp = a_pos[i] + shift;
+                const bool v = a_ok[i] && sp >= 0 && sp < Lc;
+                t_boff[i] = v ? (uint32_t)(((a_row[i] + shift) * p.lda + 4 * a_kq) * 4) : BUF_OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)t_boff[i], kk0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (tid + 256 * i) * 16, kt * (X3_TILE_HALFS * 2), 0);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 x = ra[i] * X3_A_SCALE;
+            const f16x4 h = __builtin_convertvector(x, f16x4);
+            const f32x4 r = x - __builtin_convertvector(h, f32x4);       // exact in fp32
+            const f16x4 l = __builtin_convertvector(r, f16x4);
+            const int off = ((tid >> 3) + 32 * i) * X3_LDK + 4 * a_kq;
+            *reinterpret_cast<f16x4*>(Ah + off) = h;
+            *reinterpret_cast<f16x4*>(Al + off) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;                                   // 16-byte chunk of the tile: plane, n row, k octet
+            _Float16* dst = (c < 512 ? Wh : Wl) + ((c & 511) >> 2) * X3_LDK + (c & 3) * 8;
+            *reinterpret_cast<u32x4*>(dst) = rw[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch(0);
+    commit();
+    __syncthreads();
+    const int frag = (lane & 31) * X3_LDK + 8 * (lane >> 5);            // row lane & 31, k octet lane >> 5 of a 16-deep k step
+    const _Float16* Aph = Ah + wm * WTM * X3_LDK + frag;
+    const _Float16* Apl = Al + wm * WTM * X3_LDK + frag;
+    const _Float16* Bph = Wh + wn * WTN * X3_LDK + frag;
+    const _Float16* Bpl = Wl + wn * WTN * X3_LDK + frag;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) fetch(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(Aph + 32 * i * X3_LDK + 16 * ks);
+                al[i] = *reinterpret_cast<const f16x8*>(Apl + 32 * i * X3_LDK + 16 * ks);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(Bph + 32 * j * X3_LDK + 16 * ks);
+                bl[j] = *reinterpret_cast<const f16x8*>(Bpl + 32 * j * X3_LDK + 16 * ks);
+            }
+            // the two cross terms first, the leading term last: four independent accumulators per term
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                               // every wave is done reading this tile
+        if (kt + 1 < nkt) commit();
+        __syncthreads();
+    }
     gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
