@@ -57,6 +57,8 @@ def parse():
                          "this script in a subprocess after the timed region; file = profiles/r02/pmc_traffic.json")
     ap.add_argument("--cpu-impl", choices=["auto", "torch", "numpy"], default="auto",
                     help="CPU baseline on the oracle's PyTorch-CPU variant (auto: when torch is importable) or on numpy")
+    ap.add_argument("--no-split-line", action="store_true",
+                    help="skip the extra `split_precision` leg (same workload on the HUDIFF_X3=1 kernels, reported beside the f32 metric)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="2 = the batch runs as two concurrent half-batches on two streams (library default)")
@@ -149,6 +151,48 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
                       f"CPUs, {threads} threads used; {rows} rows x {steps} denoiser steps in {dt_b:.1f} s and 1 row x {steps1} "
                       f"steps in {dt_1:.1f} s (B = 1 is the reference CLI's default), philox dropout, extrapolated to the "
                       f"mean T = {mean_T:.1f} steps per sequence"}
+
+
+def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows):
+    """The same workload on the split-precision GEMM kernels (HUDIFF_X3=1: three fp16 MFMAs with fp32 accumulation per fp32
+    product, hd_kernels.hip.h gemm_x3_k).  Reported BESIDE the metric, never as it: the f32 line above is the product path."""
+    import hudiff_amd
+    B = args.batch
+    prev = os.environ.get("HUDIFF_X3")
+    os.environ["HUDIFF_X3"] = "1"
+    try:
+        model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
+        model.load_state_dict(sd)
+    finally:
+        if prev is None:
+            os.environ.pop("HUDIFF_X3", None)
+        else:
+            os.environ["HUDIFF_X3"] = prev
+    ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
+    logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
+    dmax = float(np.abs(logits - ref_logits).max())
+    model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
+                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph, lanes=args.lanes)
+    gpu_ms = 0.0
+    for i in range(-args.warmup, args.steps):
+        model.sample_restart(2023 + 7919 * i)
+        if i == 0:
+            model.sync()
+            t0 = time.perf_counter()
+        model.sample_run(0, Tmax)
+        if i >= 0:
+            model.sync()
+            gpu_ms += model.last_run_ms()[0]
+    elapsed = time.perf_counter() - t0
+    tokens = model.sample_end()
+    model.close()
+    tf = float(T.sum()) * flops_row * args.steps / (gpu_ms * 1e-3) / 1e12
+    return tokens, {"value": round(B * args.steps / elapsed, 4), "unit": "sequences/s", "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                    "dtype": "fp32 operands split as fp16 hi + fp16 lo, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
+                    "algorithmic_tflops": round(tf, 3), "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
+                    "max_abs_dlogit_vs_f32_path": dmax, "dlogit_rows": ref_rows,
+                    "note": "HUDIFF_X3=1 prototype (DESIGN.md section 9): Q|K|V, out-projection, FF and tap GEMMs; the remaining "
+                            "kernels are the f32 ones.  Not the metric."}
 
 
 def live_traffic(args, kind, mode, n_steps=4):
@@ -271,6 +315,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tokens = model.sample_end()
+    split = None
+    if rank == 0 and world == 1 and args.max_t == 0 and not args.no_split_line and os.environ.get("HUDIFF_X3", "0") in ("", "0"):
+        ref_rows = min(B, 32)
+        ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
+        ref_logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023,
+                           row0=rank * B, step=0)
+        x3_tokens, split = split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows)
+        split["rows_with_identical_tokens"] = f"{int((x3_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)"
 
     # ---- the single collective of the job: gather the final tokens on rank 0 (RCCL over xGMI) ----------
     gathered = [tokens]
@@ -342,6 +394,8 @@ def main():
                                                        f"taken at commit {tr.get('git_head', '?')}")
             except Exception:
                 pass
+        if split is not None:
+            out["split_precision"] = split
         if args.max_t > 0:
             out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
         if not args.no_cpu_baseline and n_gpus == 1:

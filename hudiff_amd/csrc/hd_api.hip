@@ -422,7 +422,7 @@ struct X3Packer {
         const int nt = N / X3_BN, kt = Ktot / X3_BK;
         o.seg_stride = (long)nt * kt * X3_TILE_HALFS;
         o.ntile_stride = (long)kt * X3_TILE_HALFS;
-        o.acc_scale = ldexpf(1.f, -shift) / X3_A_SCALE;
+        o.acc_scale = ldexpf(1.f, -shift);
         buf.resize(o.off + (size_t)nseg * o.seg_stride);
         for (int sgi = 0; sgi < nseg; ++sgi) {
             const float* ws = w.data() + (size_t)sgi * Ktot * N;
@@ -692,8 +692,12 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     return p;
 }
 
-static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
-    if (!x.w) return;
+// HUDIFF_X3_MASK (ablation aid): bit per GEMM family that may take the split-precision kernel --
+// 1 tap GEMMs, 2 Q|K|V projections, 4 attention out-projections, 8 FF1, 16 FF2, 32 pruned-tail K projection
+enum { X3_CONV = 1, X3_QKV = 2, X3_WO = 4, X3_FF1 = 8, X3_FF2 = 16, X3_PRUNEK = 32 };
+static void use_x3(GemmP& p, const X3W& x, int family, int ntile0 = 0) {
+    static const int mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 0x7fffffff; }();
+    if (!x.w || !(mask & family)) return;
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
 }
 
@@ -772,6 +776,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;
         q.sg = run;
+        q.row_mul = (q.ln_fold || q.xs_part) ? 1 : 0;
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
         q.tiles0 = (rows0 + X3_BM - 1) / X3_BM;
         q.tiles_m = q.tiles0 + (rows1 + X3_BM - 1) / X3_BM;
@@ -780,7 +785,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         if (conv) hipLaunchKernelGGL((gemm_x3_k<true>), grid, blk, 0, st, q);
         else hipLaunchKernelGGL((gemm_x3_k<false>), grid, blk, 0, st, q);
     } else {
-    p.Wx = nullptr;
+    p.Wx = nullptr; p.xs_part = nullptr; p.row_mul = 0;
     if (big && fast_ok && tiles128 < small_tiles) {
         // few 128-row tiles (narrow outputs of the token encoder): 64-row tiles balance the 256 CUs better
         launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
@@ -848,7 +853,7 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    use_x3(p, w.wcx);
+    use_x3(p, w.wcx, X3_CONV);
     launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
@@ -870,7 +875,10 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
     if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
-    use_x3(p, w.wqkvx);
+    else if (m->x3 && cur(m).ws.part_last) {            // raw residual stream: its producer's partials give the split a per-row scale
+        p.xs_part = cur(m).ws.part_last; p.xs_pw = cur(m).ws.part_last_pw; p.xs_rows = (long)sg.B * sg.L;
+    }
+    use_x3(p, w.wqkvx, X3_QKV);
     launch_gemm(m, p, false, false);
     const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
@@ -881,7 +889,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p = base_gemm(m, sg);
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    use_x3(p, w.wox);
+    use_x3(p, w.wox, X3_WO);
     launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
@@ -922,7 +930,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.N = via_rows ? A : 2 * A; p.Kc = D; p.ln_fold = 1;
     use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
     const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
-    use_x3(p, w.a2.wqkvx, A / X3_BN);           // column slice [A, ...) of the fused matrix = n tiles from A / 128 on
+    use_x3(p, w.a2.wqkvx, X3_PRUNEK, A / X3_BN);           // column slice [A, ...) of the fused matrix = n tiles from A / 128 on
     launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -978,7 +986,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
-                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers);
+                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers || m->x3);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
         if (m->debug_stop_after == 2 + n) return HD_OK;
@@ -993,13 +1001,13 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
         p.ln_fold = 1; p.epi_act = ACT_RELU;       // LN2 folded into wf1 / bf1
         use_partials(m, p);         // statistics of `at`: partials left by the second attention's out-projection
-        use_x3(p, w.wf1x);
+        use_x3(p, w.wf1x, X3_FF1);
         launch_gemm(m, p, false, false);
         p = base_gemm(m, sg);
         p.A = ws.F1; p.lda = m->Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Y; p.ldc = D; p.N = D; p.Kc = m->Fd;
         p.resid = ws.Y; p.ldr = D;
-        use_x3(p, w.wf2x);
-        launch_gemm(m, p, false, false);
+        use_x3(p, w.wf2x, X3_FF2);
+        launch_gemm(m, p, false, false, m->x3 ? STATS_PARTIALS : STATS_NONE);     // x3: the next block's Q|K|V scales its rows by these
     }
     HIP_TRY(hipGetLastError());
     return HD_OK;

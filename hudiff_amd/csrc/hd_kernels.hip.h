@@ -138,6 +138,11 @@ struct GemmP {
     // split-precision variant (gemm_x3_k): W as pre-tiled (hi, lo) fp16 planes scaled by a power of two, per segment at
     // + seg * wx_stride halfs; acc_scale = 2^-(weight shift + activation shift) undoes the scaling in the epilogue
     const uint16_t* Wx; long wx_stride; float acc_scale;
+    // ... and, for an A operand of unbounded magnitude (the raw residual stream), the LayerNorm slice partials its
+    // producer left: gemm_x3_k derives a per-row power-of-two scale from the row's rms so that the fp16 split can neither
+    // overflow nor lose its low part (never a prologue; ignored by gemm_k).  row_mul: the epilogue multiplies each row by
+    // rowst[row].y (gemm_x3_k puts rstd-of-a-folded-LayerNorm / row scale there).
+    const float2* xs_part; int xs_pw; long xs_rows; int row_mul;
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
     float* C; int ldc;                // [rows, N]
     int N, Kc, taps, dil;             // K = taps * Kc
@@ -273,7 +278,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
                 if (p.Wx) v *= p.acc_scale;                               // split-precision operands were scaled by powers of two
-                if (p.ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
+                if (p.ln_fold || p.row_mul) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
                 if (p.resid) v += rres[it];
@@ -339,20 +344,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
 }
 
 // (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
-__device__ __forceinline__ float2 gemm_row_stat(const GemmP& p, long grow) {
-    if (!p.spart) return p.stats[grow];
-    const int Kc = p.Kc;
-    const int P = (Kc + p.spw - 1) / p.spw;
+__device__ __forceinline__ float2 merge_row_stat(const float2* __restrict__ spart, int spw, long spart_rows, int Kc, long grow) {
+    const int P = (Kc + spw - 1) / spw;
     float mean = 0.f;
-    for (int s = 0; s < P; ++s) mean += p.spart[(long)s * p.spart_rows + grow].x * (float)min(p.spw, Kc - s * p.spw);
+    for (int s = 0; s < P; ++s) mean += spart[(long)s * spart_rows + grow].x * (float)min(spw, Kc - s * spw);
     mean /= (float)Kc;
     float m2 = 0.f;
     for (int s = 0; s < P; ++s) {
-        const float2 pr = p.spart[(long)s * p.spart_rows + grow];
+        const float2 pr = spart[(long)s * spart_rows + grow];
         const float d = pr.x - mean;
-        m2 += pr.y + (float)min(p.spw, Kc - s * p.spw) * d * d;
+        m2 += pr.y + (float)min(spw, Kc - s * spw) * d * d;
     }
     return make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+}
+__device__ __forceinline__ float2 gemm_row_stat(const GemmP& p, long grow) {
+    if (!p.spart) return p.stats[grow];
+    return merge_row_stat(p.spart, p.spw, p.spart_rows, p.Kc, grow);
 }
 
 // ABLATE (probe builds only, scripts/gemm_probe.hip): 1 = no global loads inside the K loop,
@@ -676,9 +683,13 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
 // 32-cycle MFMAs cover K = 16 for which the fp32 form needs eight 64-cycle ones.
 //   Weights are split once at hd_finalize (power-of-two scaled so that the lo parts stay normal fp16 numbers, laid out
 //   as the 128 x 32 tiles the blocks consume: plain 16-byte copies into LDS); activations are split while they are
-//   staged (scaled by 2^4: |x| up to 4094 representable, lo parts exact to 2^-29 absolute); the epilogue multiplies the
-//   accumulators by GemmP::acc_scale and is otherwise the fp32 kernel's own (bias, activation, residual, dropout,
-//   addend, LayerNorm partials, folded LayerNorm).
+//   staged.  fp16 holds |x| < 65504 and loses the low part's accuracy below 2^-14, so an operand of unbounded magnitude
+//   (the raw residual stream in front of the Q|K|V and FF1 projections) is first multiplied by a per-row power of two taken
+//   from the row's rms (LayerNorm statistics its producer left: rms -> [2^6, 2^7), every element <= sqrt(K) rms < 2^12);
+//   operands that are bounded by construction (LayerNorm + activation outputs, attention outputs, ReLU(FF1)) are split
+//   as they are: below |x| = 2^-3 the low part is then exact only to 2^-25 ABSOLUTE, 1/2 ulp of an fp32 number near 1.
+//   The epilogue multiplies the accumulators by GemmP::acc_scale (weights) and the inverse row scale and is otherwise the
+//   fp32 kernel's own (bias, activation, residual, dropout, addend, LayerNorm partials, folded LayerNorm).
 // Shapes: Kc % 32 == 0, N % 128 == 0, no A prologue (LayerNorm folded or applied in place), operands < 2 GiB.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -687,7 +698,7 @@ constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32;
 constexpr int X3_LDK = X3_BK + 8;                  // LDS row stride in halfs (80 B: 16-B aligned, conflict-free ds_read_b128)
 constexpr int X3_PLANE = X3_BM * X3_LDK;           // halfs per (128 x 32) plane in LDS
 constexpr int X3_TILE_HALFS = 2 * X3_BN * X3_BK;   // one pre-tiled weight tile in global memory: hi[128][32] then lo[128][32]
-constexpr float X3_A_SCALE = 16.0f;                // activations are multiplied by 2^4 before the split
+constexpr int X3_ROW_RMS_EXP = 6;                  // per-row scaling brings the row's rms into [2^6, 2^7)
 
 template <bool CONV>
 __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
@@ -724,12 +735,23 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     const int half = (p.taps - 1) / 2;
     const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * nkt * X3_TILE_HALFS;
 
-    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
-        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+    // per row of the tile: (power-of-two scale applied to the A row before the split, factor the epilogue multiplies the
+    // row by = rstd of a folded LayerNorm / that scale)
+    float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+    const bool row_scaled = p.ln_fold || p.xs_part;
+    if (row_scaled) {
         for (int r = tid; r < BM; r += 256) {
             const int lrow = m0 + r;
-            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+            const long grow = lrow < seg_rows ? (long)rbase + lrow : (long)rbase;
+            const float2 st = p.ln_fold ? gemm_row_stat(p, grow) : merge_row_stat(p.xs_part, p.xs_pw, p.xs_rows, Kc, grow);
+            const float ms = fmaxf(1.0f / (st.y * st.y) - 1e-5f, 0.f) + st.x * st.x;      // mean square of the row
+            int e = (int)((__float_as_uint(ms) >> 23) & 0xff) - 127;                        // floor(log2(ms)), ms normal or 0
+            e = ms > 0.f ? (e >> 1) : 0;                                                    // floor(log2(rms)) (arithmetic shift)
+            const int k = min(max(X3_ROW_RMS_EXP - e, -60), 60);
+            const float sc = __uint_as_float((uint32_t)(127 + k) << 23), inv = __uint_as_float((uint32_t)(127 - k) << 23);
+            rowst[r] = make_float2(sc, (p.ln_fold ? st.y : 1.0f) * inv);
         }
+        __syncthreads();
     }
     // A staging: 128 rows x 8 float4 per k tile; thread -> k quad tid % 8, rows tid / 8 + 32 i
     constexpr uint32_t BUF_OOB = 0x80000000u;
@@ -745,6 +767,11 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
         t_boff[i] = a_ok[i] ? (uint32_t)((a_row[i] * p.lda + 4 * a_kq) * 4) : BUF_OOB;
+    }
+    float a_sc[4] = {1.f, 1.f, 1.f, 1.f};
+    if (row_scaled) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_sc[i] = rowst[(tid >> 3) + 32 * i].x;
     }
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_TILE_HALFS * 2, 0x00020000);
@@ -773,7 +800,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 x = ra[i] * X3_A_SCALE;
+            const f32x4 x = ra[i] * a_sc[i];
             const f16x4 h = __builtin_convertvector(x, f16x4);
             const f32x4 r = x - __builtin_convertvector(h, f32x4);       // exact in fp32
             const f16x4 l = __builtin_convertvector(r, f16x4);
