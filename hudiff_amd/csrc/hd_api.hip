@@ -61,7 +61,7 @@ struct X3W { const uint16_t* w = nullptr; long seg_stride = 0; float acc_scale =
 struct ByteNetW {   // one ByteNet block, both segments packed back to back
     const float *ln1_g, *ln1_b, *w1, *b1, *ln2_g, *ln2_b, *wc, *bc, *ln3_g, *ln3_b, *w3, *b3;
     int dil;
-    X3W wcx;
+    X3W wcx, w1x, w3x;
 };
 struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; X3W wqkvx, wox; };
 struct AttBlockW {
@@ -76,6 +76,7 @@ struct Workspace {
     float *FEAT = nullptr, *Y = nullptr, *G1 = nullptr, *G2 = nullptr;  // conv stage: [M,D] x2, [M,Dh] x2
     float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
+    float* S1 = nullptr;                                     // split-precision route: act(LN(x)) of a ByteNet block's input, [M,D]
     float2* ST = nullptr;
     float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
     int part_next = 0;                                       // buffer the next producing GEMM writes
@@ -362,7 +363,7 @@ static void append(std::vector<float>& a, const std::vector<float>& b) { a.inser
 
 struct X3Off;
 struct X3Packer;
-struct ByteNetOff { size_t ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3; std::vector<float> wc_copy; };
+struct ByteNetOff { size_t ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3; std::vector<float> wc_copy, w1_copy, w3_copy; };
 
 static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::string>& prefixes, int din, int dh, int ks) {
     std::vector<float> ln1_g, ln1_b, w1, b1, ln2_g, ln2_b, wc, bc, ln3_g, ln3_b, w3, b3;
@@ -378,7 +379,7 @@ static ByteNetOff pack_bytenet(Loader& ld, Packer& pk, const std::vector<std::st
     o.ln1_g = pk.add(ln1_g); o.ln1_b = pk.add(ln1_b); o.w1 = pk.add(w1); o.b1 = pk.add(b1);
     o.ln2_g = pk.add(ln2_g); o.ln2_b = pk.add(ln2_b); o.wc = pk.add(wc); o.bc = pk.add(bc);
     o.ln3_g = pk.add(ln3_g); o.ln3_b = pk.add(ln3_b); o.w3 = pk.add(w3); o.b3 = pk.add(b3);
-    o.wc_copy = wc;          // kept for the split-precision copy (hd_finalize)
+    o.wc_copy = wc; o.w1_copy = w1; o.w3_copy = w3;      // kept for the split-precision copies (hd_finalize)
     return o;
 }
 
@@ -496,9 +497,16 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         for (auto& s : segn) pf.push_back(convp + s + "." + std::to_string(n) + ".");
         conv_off.push_back(pack_bytenet(ld, pk, pf, D, Dh, ks));
     }
-    std::vector<X3Off> enc_x, conv_x;
-    for (auto& o : enc_off) { enc_x.push_back(xp ? xp->add(o.wc_copy, m->nseg, ks * dh, dh) : X3Off()); o.wc_copy.clear(); o.wc_copy.shrink_to_fit(); }
-    for (auto& o : conv_off) { conv_x.push_back(xp ? xp->add(o.wc_copy, m->nseg, ks * Dh, Dh) : X3Off()); o.wc_copy.clear(); o.wc_copy.shrink_to_fit(); }
+    struct BnX { X3Off wc, w1, w3; };
+    std::vector<BnX> enc_x, conv_x;
+    auto bnx = [&](ByteNetOff& o, int din, int dhh) {
+        BnX x;
+        if (xp) { x.wc = xp->add(o.wc_copy, m->nseg, ks * dhh, dhh); x.w1 = xp->add(o.w1_copy, m->nseg, din, dhh); x.w3 = xp->add(o.w3_copy, m->nseg, dhh, din); }
+        for (auto* v : {&o.wc_copy, &o.w1_copy, &o.w3_copy}) { v->clear(); v->shrink_to_fit(); }
+        return x;
+    };
+    for (auto& o : enc_off) enc_x.push_back(bnx(o, d, dh));
+    for (auto& o : conv_off) conv_x.push_back(bnx(o, D, Dh));
     struct AttOff { AttLayerOff a1, a2; size_t n1_g, n1_b, n2_g, n2_b, wf1, bf1, wf2, bf2; X3Off wf1x, wf2x; };
     std::vector<AttOff> att_off;
     for (int n = 0; n < c.cs_layers; ++n) {
@@ -601,8 +609,14 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
                    B0 + o.ln3_g, B0 + o.ln3_b, B0 + o.w3, B0 + o.b3, dilation_of(c, n)};
         return w;
     };
-    for (int n = 0; n < c.n_encoder_layers; ++n) { m->enc.push_back(mk(enc_off[n], n)); m->enc.back().wcx = mkx(enc_x[n]); }
-    for (int n = 0; n < c.dual_layers; ++n) { m->conv.push_back(mk(conv_off[n], n)); m->conv.back().wcx = mkx(conv_x[n]); }
+    for (int n = 0; n < c.n_encoder_layers; ++n) {
+        m->enc.push_back(mk(enc_off[n], n));
+        m->enc.back().wcx = mkx(enc_x[n].wc); m->enc.back().w1x = mkx(enc_x[n].w1); m->enc.back().w3x = mkx(enc_x[n].w3);
+    }
+    for (int n = 0; n < c.dual_layers; ++n) {
+        m->conv.push_back(mk(conv_off[n], n));
+        m->conv.back().wcx = mkx(conv_x[n].wc); m->conv.back().w1x = mkx(conv_x[n].w1); m->conv.back().w3x = mkx(conv_x[n].w3);
+    }
     for (auto& o : att_off) {
         AttBlockW w;
         w.a1 = {B0 + o.a1.wqkv, B0 + o.a1.bqkv, B0 + o.a1.wo, B0 + o.a1.bo, mkx(o.a1.wqkvx), mkx(o.a1.wox)};
@@ -666,6 +680,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
     HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART[0], M * PART_STRIDE)); HD_TRY(dalloc(ws, &ws.PART[1], M * PART_STRIDE));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
+    if (m->x3) HD_TRY(dalloc(ws, &ws.S1, M * D));
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
     HD_TRY(dalloc(ws, &ws.PW, (size_t)B * m->cfg.nhead * 320)); HD_TRY(dalloc(ws, &ws.YV, (size_t)B * m->cfg.nhead * m->D));
@@ -693,8 +708,9 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
 }
 
 // HUDIFF_X3_MASK (ablation aid): bit per GEMM family that may take the split-precision kernel --
-// 1 tap GEMMs, 2 Q|K|V projections, 4 attention out-projections, 8 FF1, 16 FF2, 32 pruned-tail K projection
-enum { X3_CONV = 1, X3_QKV = 2, X3_WO = 4, X3_FF1 = 8, X3_FF2 = 16, X3_PRUNEK = 32 };
+// 1 tap GEMMs, 2 Q|K|V projections, 4 attention out-projections, 8 FF1, 16 FF2, 32 pruned-tail K projection,
+// 64 / 128 ByteNet PFF1 / PFF3 (LayerNorm + activation prologue)
+enum { X3_CONV = 1, X3_QKV = 2, X3_WO = 4, X3_FF1 = 8, X3_FF2 = 16, X3_PRUNEK = 32, X3_PFF1 = 64, X3_PFF3 = 128 };
 static void use_x3(GemmP& p, const X3W& x, int family, int ntile0 = 0) {
     static const int mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 0x7fffffff; }();
     if (!x.w || !(mask & family)) return;
@@ -770,8 +786,8 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     p.a_bytes = fast_ok ? (uint32_t)(rows * lda * 4) : 0;
     p.w_bytes = fast_ok ? (uint32_t)((long)p.taps * p.Kc * ldw * 4) : 0;
     // split-precision variant: big launches without an A prologue whose shape the 128 x 128 x 32 tiles cover exactly
-    const bool no_pro = p.ln_fold || (!p.stats && !p.spart);
-    if (p.Wx && big && fast_ok && no_pro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
+    const int xpro = (!p.ln_fold && (p.stats || p.spart)) ? 1 + p.pro_act : 0;      // an A prologue: fp32 kernels only
+    if (p.Wx && big && fast_ok && !xpro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
         Segs run = p.sg;
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;
@@ -782,8 +798,12 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         q.tiles_m = q.tiles0 + (rows1 + X3_BM - 1) / X3_BM;
         q.tiles_n = q.N / X3_BN;
         dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
-        if (conv) hipLaunchKernelGGL((gemm_x3_k<true>), grid, blk, 0, st, q);
-        else hipLaunchKernelGGL((gemm_x3_k<false>), grid, blk, 0, st, q);
+        static const size_t dyn = [] { const char* e = getenv("HUDIFF_X3_DYNLDS"); return e ? (size_t)atoi(e) : (size_t)0; }();   // occupancy experiments
+        static const int dbg_sync = [] { const char* e = getenv("HUDIFF_X3_SYNC"); return e ? atoi(e) : 0; }();
+        if (dbg_sync & 1) hipStreamSynchronize(st);
+        if (conv) hipLaunchKernelGGL((gemm_x3_k<true>), grid, blk, dyn, st, q);
+        else hipLaunchKernelGGL((gemm_x3_k<false>), grid, blk, dyn, st, q);
+        if (dbg_sync & 2) hipStreamSynchronize(st);
     } else {
     p.Wx = nullptr; p.xs_part = nullptr; p.row_mul = 0;
     if (big && fast_ok && tiles128 < small_tiles) {
@@ -802,7 +822,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     if (apply) {      // normalise + activate the output in place (consumer: the tap GEMM, which then needs no prologue)
         const int seg1 = p.sg.nseg > 1 ? p.sg.base[1] : (int)rows;
         hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, pw, p.N, (int)rows,
-                           p.C, apply->gamma, apply->beta, apply->k_stride, seg1, apply->act);
+                           (const float*)p.C, p.ldc, p.C, p.ldc, (const float2*)nullptr, apply->gamma, apply->beta, apply->k_stride, seg1, apply->act);
     }
 }
 
@@ -841,6 +861,41 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
     if (x_stats == X_NONE) launch_stats(m, x, ldx, din, rows, cur(m).stream);
+    if (m->x3 && w.w1x.w && w.w3x.w && rows >= 8192 && cur(m).ws.S1) {
+        // Split-precision route: the operands of PFF1 / PFF3 are normalised + activated ONCE by ln_apply_k (out of place for
+        // x, which the residual still needs; in place for h2) and both projections run without a prologue -- the fp32
+        // route recomputes LayerNorm + activation in every N tile's prologue, which costs more than the MFMAs once those
+        // are three fp16 instructions.
+        Workspace& ws = cur(m).ws;
+        hipStream_t st = cur(m).stream;
+        const int seg1 = sg.nseg > 1 ? sg.base[1] : rows;
+        const bool from_part = x_stats == X_PARTIALS;
+        hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
+                           ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
+                           w.ln1_g, w.ln1_b, din, seg1, act);
+        GemmP p = base_gemm(m, sg);
+        p.A = ws.S1; p.lda = din; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
+        p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
+        const LnApply ap2{w.ln2_g, w.ln2_b, dh, act};
+        use_x3(p, w.w1x, X3_PFF1);
+        launch_gemm(m, p, false, true, STATS_NONE, &ap2);
+
+        p = base_gemm(m, sg);
+        p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
+        p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
+        const LnApply ap3{w.ln3_g, w.ln3_b, dh, act};
+        use_x3(p, w.wcx, X3_CONV);
+        launch_gemm(m, p, true, true, STATS_NONE, &ap3);
+
+        p = base_gemm(m, sg);
+        p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
+        p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
+        p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
+        use_x3(p, w.w3x, X3_PFF3);
+        set_drop(p, dr);
+        launch_gemm(m, p, false, true, want_out_stats ? STATS_PARTIALS : STATS_NONE);
+        return;
+    }
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = ldx; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
     p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;

@@ -700,6 +700,8 @@ constexpr int X3_PLANE = X3_BM * X3_LDK;           // halfs per (128 x 32) plane
 constexpr int X3_TILE_HALFS = 2 * X3_BN * X3_BK;   // one pre-tiled weight tile in global memory: hi[128][32] then lo[128][32]
 constexpr int X3_ROW_RMS_EXP = 6;                  // per-row scaling brings the row's rms into [2^6, 2^7)
 
+// There is no A prologue: where the fp32 path normalises the operand while staging it (ByteNet PFF1 / PFF3), the
+// split-precision path normalises it once with ln_apply_k and multiplies the result.
 template <bool CONV>
 __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     constexpr int BM = X3_BM, BN = X3_BN, BK = X3_BK, WM = 2, WN = 2;
@@ -773,6 +775,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a_sc[i] = rowst[(tid >> 3) + 32 * i].x;
     }
+
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_TILE_HALFS * 2, 0x00020000);
     f32x4 ra[4];
@@ -873,33 +876,33 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 // used in front of the dilated convolution, which would otherwise redo the normalisation and the (erf) GELU
 // for each of its 7 taps and each of its N tiles.  One wave per row; gamma / beta are per chain segment.
 // ------------------------------------------------------------------------------------------------
+// `stats` (ready-made (mean, rstd) per row) may replace the partials; Y / ldy: output rows (== X, ldx for in place).
 __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ part, int pw, int C, int rows,
-                                                   float* __restrict__ X, const float* __restrict__ gamma,
+                                                   const float* X, int ldx, float* Y, int ldy, const float2* __restrict__ stats,
+                                                   const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, int k_stride, int seg1_row0,
                                                    int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const int P = (C + pw - 1) / pw;
-    float mean = 0.f;
-    for (int i = 0; i < P; ++i) mean += part[(long)i * rows + row].x * (float)min(pw, C - i * pw);
-    mean /= (float)C;
-    float m2 = 0.f;
-    for (int i = 0; i < P; ++i) {
-        const float2 pr = part[(long)i * rows + row];
-        const float d = pr.x - mean;
-        m2 += pr.y + (float)min(pw, C - i * pw) * d * d;
+    float mean, rstd;
+    if (stats) {
+        const float2 st = stats[row];
+        mean = st.x; rstd = st.y;
+    } else {
+        const float2 st = merge_row_stat(part, pw, rows, C, row);
+        mean = st.x; rstd = st.y;
     }
-    const float rstd = 1.0f / sqrtf(m2 / (float)C + 1e-5f);
     const int seg = row >= seg1_row0 ? 1 : 0;
     const float* g = gamma + seg * k_stride;
     const float* b = beta + seg * k_stride;
-    float* x = X + (long)row * C;
+    const float* x = X + (long)row * ldx;
+    float* y = Y + (long)row * ldy;
     for (int c = lane * 4; c < C; c += 256) {
-        f32x4 v = *reinterpret_cast<f32x4*>(x + c);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c), bv = *reinterpret_cast<const f32x4*>(b + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = act_f((v[k] - mean) * rstd * gv[k] + bv[k], act);
-        *reinterpret_cast<f32x4*>(x + c) = v;
+        *reinterpret_cast<f32x4*>(y + c) = v;
     }
 }
 
