@@ -430,13 +430,16 @@ struct X3Packer {
             uint16_t* dst = buf.data() + o.off + (size_t)sgi * o.seg_stride;
             for (int a = 0; a < nt; ++a)
                 for (int b = 0; b < kt; ++b) {
+                    // the tile is the LDS image gemm_x3_k copies with linear 16-byte DMA pieces: row n = 32 halfs (64 B), its
+                    // four 8-half chunks XOR-swizzled by (n >> 2) & 3 (conflict-free ds_read_b128 without padding)
                     uint16_t* t = dst + ((size_t)a * kt + b) * X3_TILE_HALFS;
                     for (int n = 0; n < X3_BN; ++n)
                         for (int k = 0; k < X3_BK; ++k) {
                             const float v = ws[(size_t)(b * X3_BK + k) * N + a * X3_BN + n] * sc;
                             const float hi = f16(v);
-                            t[n * X3_BK + k] = h16(hi);
-                            t[X3_BN * X3_BK + n * X3_BK + k] = h16(v - hi);
+                            const int pos = n * X3_BK + ((((k >> 3) ^ ((n >> 2) & 3)) << 3) | (k & 7));
+                            t[pos] = h16(hi);
+                            t[X3_BN * X3_BK + pos] = h16(v - hi);
                         }
                 }
         }
@@ -787,7 +790,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     p.w_bytes = fast_ok ? (uint32_t)((long)p.taps * p.Kc * ldw * 4) : 0;
     // split-precision variant: big launches without an A prologue whose shape the 128 x 128 x 32 tiles cover exactly
     const int xpro = (!p.ln_fold && (p.stats || p.spart)) ? 1 + p.pro_act : 0;      // an A prologue: fp32 kernels only
-    if (p.Wx && big && fast_ok && !xpro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
+    if (p.Wx && big && fast_ok && !xpro && p.Kc % X3_BK == 0 && ((long)p.taps * p.Kc / X3_BK) % 2 == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
         Segs run = p.sg;
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;

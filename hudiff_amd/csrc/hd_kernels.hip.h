@@ -702,22 +702,40 @@ constexpr int X3_ROW_RMS_EXP = 6;                  // per-row scaling brings the
 
 // There is no A prologue: where the fp32 path normalises the operand while staging it (ByteNet PFF1 / PFF3), the
 // split-precision path normalises it once with ln_apply_k and multiplies the result.
+// K loop (k tile = 32): the weight tile of k tile kt+1 travels global -> LDS by DMA (buffer_load ... lds, no registers, no
+// ds_write) into the other of two LDS buffers while tile kt is multiplied; its rows are 64 B with the 16-byte chunks
+// XOR-swizzled by (n >> 2) & 3 -- baked into the global tile image at hd_finalize -- so that the ds_read_b128 of a fragment
+// is conflict-free without padding.  The fp32 A rows are fetched into registers TWO tiles ahead (two register sets, the loop
+// is unrolled by two: nkt must be even), split into (hi, lo) after the MFMAs of the current tile and written to the single
+// A buffer between the two barriers of a tile.
+constexpr int X3_WTILE_BYTES = X3_TILE_HALFS * 2;  // 16 KiB
+// Block barrier that waits for this wave's LDS instructions only (lgkmcnt(0)): __syncthreads() -- and any fence the
+// compiler can see -- would also drain every outstanding vector-memory instruction at each of the two barriers of a tile,
+// i.e. the A rows prefetched two tiles ahead and the weight DMA in flight.  The DMA (a vector-memory instruction that
+// writes LDS) is waited for explicitly with s_waitcnt vmcnt where its data is needed; the empty asm statements keep the
+// compiler from moving LDS accesses across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 template <bool CONV>
 __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     constexpr int BM = X3_BM, BN = X3_BN, BK = X3_BK, WM = 2, WN = 2;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
     constexpr int EPI_FLOATS = 4 * 32 * ES, PART_FLOATS = 4 * WTM * 2;
-    constexpr int LOOP_FLOATS = 4 * X3_PLANE / 2;
+    constexpr int A_FLOATS = 2 * X3_PLANE / 2;                    // A hi + lo planes, padded rows
+    constexpr int LOOP_FLOATS = A_FLOATS + 2 * X3_WTILE_BYTES / 4;   // + two weight tile buffers
     constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
     _Float16* Al = Ah + X3_PLANE;
-    _Float16* Wh = Al + X3_PLANE;
-    _Float16* Wl = Wh + X3_PLANE;
+    char* Wb = reinterpret_cast<char*>(smem + A_FLOATS);          // buffer b at Wb + b * X3_WTILE_BYTES: hi plane, then lo plane
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int bx, by, seg = 0;
     {
@@ -733,7 +751,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     const int m0 = bx * BM, n0 = by * BN;
     const int Kc = p.Kc;
     const int nkt_tap = Kc / BK;
-    const int nkt = nkt_tap * p.taps;
+    const int nkt = nkt_tap * p.taps;                  // even (host-checked)
     const int half = (p.taps - 1) / 2;
     const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * nkt * X3_TILE_HALFS;
 
@@ -775,13 +793,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a_sc[i] = rowst[(tid >> 3) + 32 * i].x;
     }
-
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_TILE_HALFS * 2, 0x00020000);
-    f32x4 ra[4];
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rw[4];
-    auto fetch = [&](int kt) {
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_WTILE_BYTES, 0x00020000);
+    auto fetch_a = [&](int kt, f32x4 (&ra)[4]) {
         const int tap = CONV ? kt / nkt_tap : 0;
         const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
         if (CONV && kk0 == 0) {                        // first k tile of a tap: row shift + zero padding at the chain ends
@@ -796,11 +810,18 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)t_boff[i], kk0 * 4, 0));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (tid + 256 * i) * 16, kt * (X3_TILE_HALFS * 2), 0);
     };
-    auto commit = [&]() {
+    // weight tile kt -> LDS buffer `buf`: each wave copies 4 x 1 KiB (lane l -> 16 bytes at piece base + 16 l), linear image
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    auto dma_w = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = i * 4 + wave;                                  // 16 pieces of 1 KiB
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(Wb + buf * X3_WTILE_BYTES + piece * 1024), 16,
+                                                 piece * 1024 + lane * 16, kt * X3_WTILE_BYTES, 0, 0);
+        }
+    };
+    auto commit_a = [&](const f32x4 (&ra)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 x = ra[i] * a_sc[i];
@@ -810,12 +831,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
             const int off = ((tid >> 3) + 32 * i) * X3_LDK + 4 * a_kq;
             *reinterpret_cast<f16x4*>(Ah + off) = h;
             *reinterpret_cast<f16x4*>(Al + off) = l;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;                                   // 16-byte chunk of the tile: plane, n row, k octet
-            _Float16* dst = (c < 512 ? Wh : Wl) + ((c & 511) >> 2) * X3_LDK + (c & 3) * 8;
-            *reinterpret_cast<u32x4*>(dst) = rw[i];
         }
     };
 
@@ -827,16 +842,15 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    fetch(0);
-    commit();
-    __syncthreads();
-    const int frag = (lane & 31) * X3_LDK + 8 * (lane >> 5);            // row lane & 31, k octet lane >> 5 of a 16-deep k step
-    const _Float16* Aph = Ah + wm * WTM * X3_LDK + frag;
-    const _Float16* Apl = Al + wm * WTM * X3_LDK + frag;
-    const _Float16* Bph = Wh + wn * WTN * X3_LDK + frag;
-    const _Float16* Bpl = Wl + wn * WTN * X3_LDK + frag;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch(kt + 1);
+    const int afrag = (lane & 31) * X3_LDK + 8 * (lane >> 5);           // row lane & 31, k octet lane >> 5 of a 16-deep k step
+    const _Float16* Aph = Ah + wm * WTM * X3_LDK + afrag;
+    const _Float16* Apl = Al + wm * WTM * X3_LDK + afrag;
+    // weight fragment: row n = wn * 64 + 32 j + (lane & 31) at n * 64 bytes, chunk (2 ks + g) stored at slot chunk ^ ((n >> 2) & 3)
+    const int wf = (lane >> 2) & 3, wg = lane >> 5;
+    const int wrow = (wn * WTN + (lane & 31)) * 64;
+    const int woff0 = wrow + (((0 + wg) ^ wf) << 4), woff1 = wrow + (((2 + wg) ^ wf) << 4);
+    auto mma = [&](int buf) {
+        const char* Wt = Wb + buf * X3_WTILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -847,8 +861,9 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8*>(Bph + 32 * j * X3_LDK + 16 * ks);
-                bl[j] = *reinterpret_cast<const f16x8*>(Bpl + 32 * j * X3_LDK + 16 * ks);
+                const int o = (ks ? woff1 : woff0) + 32 * 64 * j;
+                bh[j] = *reinterpret_cast<const f16x8*>(Wt + o);
+                bl[j] = *reinterpret_cast<const f16x8*>(Wt + X3_WTILE_BYTES / 2 + o);
             }
             // the two cross terms first, the leading term last: four independent accumulators per term
 #pragma unroll
@@ -864,10 +879,33 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();                               // every wave is done reading this tile
-        if (kt + 1 < nkt) commit();
-        __syncthreads();
+    };
+    // one k tile: `cur` holds A(kt+1) (fetched a tile ago), `nxt` receives A(kt+2); weights of tile kt sit in buffer wb
+    auto step = [&](int kt, f32x4 (&cur)[4], f32x4 (&nxt)[4], int wb) {
+        const bool more = kt + 1 < nkt, more2 = kt + 2 < nkt;
+        if (more) dma_w(kt + 1, wb ^ 1);               // that buffer was last read in tile kt-1: every wave is past its barrier
+        if (more2) fetch_a(kt + 2, nxt);
+        mma(wb);
+        lds_barrier();                                 // every wave is done reading the A planes of this tile
+        if (more) commit_a(cur);
+        // the weight DMA of tile kt+1 must have landed before anyone reads it: everything issued before the (up to) four
+        // A loads of tile kt+2 has to be back
+        if (more2) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+        lds_barrier();
+    };
+    f32x4 ra0[4], ra1[4];
+    fetch_a(0, ra0);
+    dma_w(0, 0);
+    if (nkt > 1) fetch_a(1, ra1);
+    commit_a(ra0);
+    if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    lds_barrier();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        step(kt, ra1, ra0, 0);
+        step(kt + 1, ra0, ra1, 1);
     }
+    __syncthreads();
     gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
