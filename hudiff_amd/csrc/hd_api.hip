@@ -76,7 +76,7 @@ struct Workspace {
     float *FEAT = nullptr, *Y = nullptr, *G1 = nullptr, *G2 = nullptr;  // conv stage: [M,D] x2, [M,Dh] x2
     float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
-    float* S1 = nullptr;                                     // split-precision route: act(LN(x)) of a ByteNet block's input, [M,D]
+    float *S1 = nullptr, *YX = nullptr, *ATX = nullptr;      // split-precision route: act(LN(x)) of a ByteNet block's input; split copies of Y / AT, [M,D]
     float2* ST = nullptr;
     float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
     int part_next = 0;                                       // buffer the next producing GEMM writes
@@ -481,6 +481,10 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     X3Packer xpk;
     { const char* e = getenv("HUDIFF_X3"); m->x3 = e && atoi(e) != 0; }
     X3Packer* xp = m->x3 ? &xpk : nullptr;
+    // HUDIFF_X3_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
+    const int x3_mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 3; }();
+    X3Packer* xp_bn = (x3_mask & 1) ? xp : nullptr;
+    X3Packer* xp_at = (x3_mask & 2) ? xp : nullptr;
     const bool ab = c.kind == HD_KIND_ANTIBODY;
     const std::vector<std::string> segn = ab ? std::vector<std::string>{"h_layers", "l_layers"} : std::vector<std::string>{"layers"};
     const std::string convp = ab ? "dual_conv_block." : "nano_conv_block.";
@@ -504,7 +508,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     std::vector<BnX> enc_x, conv_x;
     auto bnx = [&](ByteNetOff& o, int din, int dhh) {
         BnX x;
-        if (xp) { x.wc = xp->add(o.wc_copy, m->nseg, ks * dhh, dhh); x.w1 = xp->add(o.w1_copy, m->nseg, din, dhh); x.w3 = xp->add(o.w3_copy, m->nseg, dhh, din); }
+        if (xp_bn) { x.wc = xp_bn->add(o.wc_copy, m->nseg, ks * dhh, dhh); x.w1 = xp_bn->add(o.w1_copy, m->nseg, din, dhh); x.w3 = xp_bn->add(o.w3_copy, m->nseg, dhh, din); }
         for (auto* v : {&o.wc_copy, &o.w1_copy, &o.w3_copy}) { v->clear(); v->shrink_to_fit(); }
         return x;
     };
@@ -518,20 +522,20 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         // norm_hl1 is folded into the second attention's Q|K|V projection, norm_hl2 into the first FF layer
         const std::vector<float> n1g = ld.vec(p + "norm_hl1.weight", D), n1b = ld.vec(p + "norm_hl1.bias", D);
         const std::vector<float> n2g = ld.vec(p + "norm_hl2.weight", D), n2b = ld.vec(p + "norm_hl2.bias", D);
-        o.a1 = pack_attlayer(ld, pk, xp, p + "attn_hl.", D, A);
-        o.a2 = pack_attlayer(ld, pk, xp, p + "attn_hl_c.", D, A, &n1g, &n1b);
+        o.a1 = pack_attlayer(ld, pk, xp_at, p + "attn_hl.", D, A);
+        o.a2 = pack_attlayer(ld, pk, xp_at, p + "attn_hl_c.", D, A, &n1g, &n1b);
         o.n1_g = pk.add(n1g); o.n1_b = pk.add(n1b);
         o.n2_g = pk.add(n2g); o.n2_b = pk.add(n2b);
         {
             std::vector<float> wf1 = ld.lin_t(p + "ff_hl.0.weight", Fd, D), bf1 = ld.vec(p + "ff_hl.0.bias", Fd);
             fold_layernorm(wf1, bf1, n2g, n2b, D, Fd);
             o.wf1 = pk.add(wf1); o.bf1 = pk.add(bf1);
-            if (xp) o.wf1x = xp->add(wf1, 1, D, Fd);
+            if (xp_at) o.wf1x = xp_at->add(wf1, 1, D, Fd);
         }
         {
             const std::vector<float> wf2 = ld.lin_t(p + "ff_hl.2.weight", D, Fd);
             o.wf2 = pk.add(wf2); o.bf2 = pk.add(ld.vec(p + "ff_hl.2.bias", D));
-            if (xp) o.wf2x = xp->add(wf2, 1, Fd, D);
+            if (xp_at) o.wf2x = xp_at->add(wf2, 1, Fd, D);
         }
         att_off.push_back(o);
     }
@@ -683,7 +687,7 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
     HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART[0], M * PART_STRIDE)); HD_TRY(dalloc(ws, &ws.PART[1], M * PART_STRIDE));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
-    if (m->x3) HD_TRY(dalloc(ws, &ws.S1, M * D));
+    if (m->x3) { HD_TRY(dalloc(ws, &ws.S1, M * D)); HD_TRY(dalloc(ws, &ws.YX, M * D)); HD_TRY(dalloc(ws, &ws.ATX, M * D)); }
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
     HD_TRY(dalloc(ws, &ws.PW, (size_t)B * m->cfg.nhead * 320)); HD_TRY(dalloc(ws, &ws.YV, (size_t)B * m->cfg.nhead * m->D));
@@ -710,13 +714,12 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
     return p;
 }
 
-// HUDIFF_X3_MASK (ablation aid): bit per GEMM family that may take the split-precision kernel --
-// 1 tap GEMMs, 2 Q|K|V projections, 4 attention out-projections, 8 FF1, 16 FF2, 32 pruned-tail K projection,
-// 64 / 128 ByteNet PFF1 / PFF3 (LayerNorm + activation prologue)
-enum { X3_CONV = 1, X3_QKV = 2, X3_WO = 4, X3_FF1 = 8, X3_FF2 = 16, X3_PRUNEK = 32, X3_PFF1 = 64, X3_PFF3 = 128 };
-static void use_x3(GemmP& p, const X3W& x, int family, int ntile0 = 0) {
-    static const int mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 0x7fffffff; }();
-    if (!x.w || !(mask & family)) return;
+// Split-precision launches (gemm_x3_k): the A operand must already be in split form, so the decision is taken by the
+// caller BEFORE it asks the producer for split rows -- x3_use() holds every condition launch_gemm checks again.
+static bool x3_use(const HdModel* m, const Segs& sg, const X3W& x) {
+    return m->x3 && x.w && (long)sg.B * sg.L >= 8192 && (long)sg.B * sg.L * 1536 * 4 < (1L << 31);
+}
+static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
 }
 
@@ -768,7 +771,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
 #undef HD_LAUNCH
 
 // p.part != nullptr: the epilogue leaves LayerNorm partials of the output rows and they are merged into `stats_out`.
-struct LnApply { const float* gamma = nullptr; const float* beta = nullptr; int k_stride = 0; int act = 0; };
+struct LnApply { const float* gamma = nullptr; const float* beta = nullptr; int k_stride = 0; int act = 0; int split = 0; };
 enum StatsOut { STATS_NONE = 0, STATS_PARTIALS = 1 };
 
 // Output LayerNorm statistics: STATS_PARTIALS leaves the epilogue's slice partials for a consumer GEMM that merges
@@ -788,27 +791,43 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     const bool fast_ok = p.Kc % 16 == 0 && rows * lda * 4 < (1L << 31) && (long)p.taps * p.Kc * ldw * 4 < (1L << 31);
     p.a_bytes = fast_ok ? (uint32_t)(rows * lda * 4) : 0;
     p.w_bytes = fast_ok ? (uint32_t)((long)p.taps * p.Kc * ldw * 4) : 0;
-    // split-precision variant: big launches without an A prologue whose shape the 128 x 128 x 32 tiles cover exactly
-    const int xpro = (!p.ln_fold && (p.stats || p.spart)) ? 1 + p.pro_act : 0;      // an A prologue: fp32 kernels only
-    if (p.Wx && big && fast_ok && !xpro && p.Kc % X3_BK == 0 && ((long)p.taps * p.Kc / X3_BK) % 2 == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31)) {
+    // split-precision variant (p.Wx set by the caller after x3_use(); its A operand is in split form)
+    if (p.Wx) {
+        const int xpro = (!p.ln_fold && (p.stats || p.spart)) ? 1 : 0;
+        if (!(big && fast_ok && !xpro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31))) {
+            // cannot happen for shapes x3_use() admits; never fall back silently on an operand that is not fp32
+            fprintf(stderr, "libhudiff_hip: split-precision launch with an ineligible shape (rows %ld Kc %d N %d taps %d)\n", rows, p.Kc, p.N, p.taps);
+            abort();
+        }
         Segs run = p.sg;
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;
         q.sg = run;
-        q.row_mul = (q.ln_fold || q.xs_part) ? 1 : 0;
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
-        q.tiles0 = (rows0 + X3_BM - 1) / X3_BM;
-        q.tiles_m = q.tiles0 + (rows1 + X3_BM - 1) / X3_BM;
-        q.tiles_n = q.N / X3_BN;
-        dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
-        static const size_t dyn = [] { const char* e = getenv("HUDIFF_X3_DYNLDS"); return e ? (size_t)atoi(e) : (size_t)0; }();   // occupancy experiments
-        static const int dbg_sync = [] { const char* e = getenv("HUDIFF_X3_SYNC"); return e ? atoi(e) : 0; }();
-        if (dbg_sync & 1) hipStreamSynchronize(st);
-        if (conv) hipLaunchKernelGGL((gemm_x3_k<true>), grid, blk, dyn, st, q);
-        else hipLaunchKernelGGL((gemm_x3_k<false>), grid, blk, dyn, st, q);
-        if (dbg_sync & 2) hipStreamSynchronize(st);
-    } else {
-    p.Wx = nullptr; p.xs_part = nullptr; p.row_mul = 0;
+        // tile shape: the largest whose launch still fills the chip (the loop is bound by bytes pulled into LDS per flop)
+        static const int force = [] { const char* e = getenv("HUDIFF_X3_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 / 512 (= 256 x 256)
+        const long t256 = (rows0 + 255) / 256 + (rows1 + 255) / 256;
+        // measured (profiles/r02): 256 x 256 tiles pay off for the widest output only (Q|K|V, N = 1536: 583 vs 650 us); for
+        // N <= 768 the one-block-per-CU kernels lose more to barrier stalls than they save in operand traffic
+        int shape = 128;
+        if (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) shape = 512;
+        if (force == 128 || (force == 256 && shape == 512) || (force == 512 && q.N % 256 == 0)) shape = force;
+        const int bm = shape == 128 ? 128 : 256, bn = shape == 512 ? 256 : 128;
+        q.tiles0 = (rows0 + bm - 1) / bm;
+        q.tiles_m = q.tiles0 + (rows1 + bm - 1) / bm;
+        q.tiles_n = q.N / bn;
+        dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n);
+        if (shape == 512) {
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, true>), grid, dim3(512), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, false>), grid, dim3(512), 0, st, q);
+        } else if (shape == 256) {
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, true>), grid, dim3(512), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, false>), grid, dim3(512), 0, st, q);
+        } else {
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false>), grid, dim3(256), 0, st, q);
+        }
+    } else
     if (big && fast_ok && tiles128 < small_tiles) {
         // few 128-row tiles (narrow outputs of the token encoder): 64-row tiles balance the 256 CUs better
         launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
@@ -819,13 +838,13 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
     }
-    }
     if (!p.part) return;
     ws.part_last = p.part; ws.part_last_pw = pw; ws.part_next ^= 1;
     if (apply) {      // normalise + activate the output in place (consumer: the tap GEMM, which then needs no prologue)
         const int seg1 = p.sg.nseg > 1 ? p.sg.base[1] : (int)rows;
         hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, pw, p.N, (int)rows,
-                           (const float*)p.C, p.ldc, p.C, p.ldc, (const float2*)nullptr, apply->gamma, apply->beta, apply->k_stride, seg1, apply->act);
+                           (const float*)p.C, p.ldc, p.C, p.ldc, (const float2*)nullptr, apply->gamma, apply->beta, apply->k_stride, seg1,
+                           apply->act, apply->split);
     }
 }
 
@@ -860,41 +879,43 @@ enum XStats { X_FINAL = 0,      // ws.ST already holds (mean, rstd)
 // once in place (ln_apply_k).  want_out_stats: leave partials of `out` for the next block's first GEMM.
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
-                          const Drop& dr, const float* extra, int lde, XStats x_stats, bool want_out_stats) {
+                          const Drop& dr, const float* extra, int lde, XStats x_stats, bool want_out_stats,
+                          float* out_split = nullptr) {
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
     if (x_stats == X_NONE) launch_stats(m, x, ldx, din, rows, cur(m).stream);
-    if (m->x3 && w.w1x.w && w.w3x.w && rows >= 8192 && cur(m).ws.S1) {
-        // Split-precision route: the operands of PFF1 / PFF3 are normalised + activated ONCE by ln_apply_k (out of place for
-        // x, which the residual still needs; in place for h2) and both projections run without a prologue -- the fp32
-        // route recomputes LayerNorm + activation in every N tile's prologue, which costs more than the MFMAs once those
-        // are three fp16 instructions.
+    if (x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && x3_use(m, sg, w.w3x) && cur(m).ws.S1) {
+        // Split-precision route.  Every GEMM operand is normalised + activated ONCE by ln_apply_k, which also writes it in
+        // split (hi, lo) form -- out of place for x (the residual needs its fp32 rows), in place for h1 and h2 -- and the three
+        // projections run on gemm_x3_k without a prologue.  (The fp32 route recomputes LayerNorm + activation in every
+        // N tile's prologue, which costs more than the MFMAs once those are three fp16 instructions.)
         Workspace& ws = cur(m).ws;
         hipStream_t st = cur(m).stream;
         const int seg1 = sg.nseg > 1 ? sg.base[1] : rows;
         const bool from_part = x_stats == X_PARTIALS;
         hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
                            ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
-                           w.ln1_g, w.ln1_b, din, seg1, act);
+                           w.ln1_g, w.ln1_b, din, seg1, act, 1);
         GemmP p = base_gemm(m, sg);
         p.A = ws.S1; p.lda = din; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
         p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
-        const LnApply ap2{w.ln2_g, w.ln2_b, dh, act};
-        use_x3(p, w.w1x, X3_PFF1);
+        const LnApply ap2{w.ln2_g, w.ln2_b, dh, act, 1};
+        use_x3(p, w.w1x);
         launch_gemm(m, p, false, true, STATS_NONE, &ap2);
 
         p = base_gemm(m, sg);
         p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
         p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-        const LnApply ap3{w.ln3_g, w.ln3_b, dh, act};
-        use_x3(p, w.wcx, X3_CONV);
+        const LnApply ap3{w.ln3_g, w.ln3_b, dh, act, 1};
+        use_x3(p, w.wcx);
         launch_gemm(m, p, true, true, STATS_NONE, &ap3);
 
         p = base_gemm(m, sg);
         p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
         p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
         p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
-        use_x3(p, w.w3x, X3_PFF3);
+        p.C2 = out_split;
+        use_x3(p, w.w3x);
         set_drop(p, dr);
         launch_gemm(m, p, false, true, want_out_stats ? STATS_PARTIALS : STATS_NONE);
         return;
@@ -911,7 +932,6 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    use_x3(p, w.wcx, X3_CONV);
     launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
@@ -920,34 +940,42 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
     use_partials(m, p);
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
+    p.C2 = out_split;
     set_drop(p, dr);
     launch_gemm(m, p, false, true, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
 // out = resid + Attn(x) (AttLayer, cross_attention.py:149-173).  ln: x is LayerNorm'ed in front of the fused Q|K|V
 // projection; the norm is folded into that projection's weights, its row statistics are the partials the previous GEMM left.
+// x3: the whole attention stage runs on the split-precision kernels.  x_split = split copy of x (written by x's producer),
+// out_split = where to leave the split copy of `out` for the next consumer (may be null).
+static bool att_x3(const HdModel* m, const Segs& sg) {
+    if (m->att.empty()) return false;
+    const AttBlockW& w = m->att[0];
+    return x3_use(m, sg, w.a1.wqkvx) && x3_use(m, sg, w.a1.wox) && x3_use(m, sg, w.a2.wqkvx) && x3_use(m, sg, w.a2.wox) &&
+           x3_use(m, sg, w.wf1x) && x3_use(m, sg, w.wf2x) && cur(m).ws.YX && cur(m).ws.ATX;
+}
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
-                            const float* resid, float* out, bool want_out_stats) {
+                            const float* resid, float* out, bool want_out_stats, bool x3 = false,
+                            const float* x_split = nullptr, float* out_split = nullptr) {
     hipStream_t st = cur(m).stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
     if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
-    else if (m->x3 && cur(m).ws.part_last) {            // raw residual stream: its producer's partials give the split a per-row scale
-        p.xs_part = cur(m).ws.part_last; p.xs_pw = cur(m).ws.part_last_pw; p.xs_rows = (long)sg.B * sg.L;
-    }
-    use_x3(p, w.wqkvx, X3_QKV);
+    if (x3) { p.A = x_split; use_x3(p, w.wqkvx); }
     launch_gemm(m, p, false, false);
     const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
     dim3 grid(sg.B * m->cfg.nhead);
+    // x3: the out-projection reads O in split form
     if (m->L > 160)
-        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
     else
-        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg);
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
     p = base_gemm(m, sg);
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
-    use_x3(p, w.wox, X3_WO);
+    if (x3) { use_x3(p, w.wox); p.C2 = out_split; }
     launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
@@ -988,7 +1016,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     p.N = via_rows ? A : 2 * A; p.Kc = D; p.ln_fold = 1;
     use_partials(m, p);             // statistics of `at`: partials left by the first attention's out-projection
     const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
-    use_x3(p, w.a2.wqkvx, X3_PRUNEK, A / X3_BN);           // column slice [A, ...) of the fused matrix = n tiles from A / 128 on
+    if (att_x3(m, sg)) { p.A = ws.ATX; use_x3(p, w.a2.wqkvx, A / X3_BN); }     // column slice [A, ...) = n tiles from A / 128 on
     launch_gemm(m, p, false, false);
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -1039,33 +1067,36 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
                       last ? ws.EXTRA : nullptr, d, n == 0 ? X_FINAL : X_PARTIALS, /*want_out_stats=*/!last);
     }
     if (m->debug_stop_after == 1) return HD_OK;
+    const bool ax3 = att_x3(m, sg);
     for (int n = 0; n < c.dual_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
+        // x3: the last block also leaves Y in split form for the first attention's Q|K|V projection
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
-                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers || m->x3);
+                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers,
+                      (ax3 && n + 1 == c.dual_layers) ? ws.YX : nullptr);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
         if (m->debug_stop_after == 2 + n) return HD_OK;
         const AttBlockW& w = m->att[n];
         // at = x + A1(x)
-        attention_layer(m, sg, w.a1, ws.Y, false, ws.Y, ws.AT, /*want_out_stats=*/true);
+        attention_layer(m, sg, w.a1, ws.Y, false, ws.Y, ws.AT, /*want_out_stats=*/true, ax3, ws.YX, ws.ATX);
         // at = at + A2(LN1(at))      (statistics of `at` come from the out-projection's epilogue)
         if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
-        attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true);
+        attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true, ax3, ws.ATX, ws.ATX);
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
         p.ln_fold = 1; p.epi_act = ACT_RELU;       // LN2 folded into wf1 / bf1
         use_partials(m, p);         // statistics of `at`: partials left by the second attention's out-projection
-        use_x3(p, w.wf1x, X3_FF1);
+        if (ax3) { p.A = ws.ATX; use_x3(p, w.wf1x); p.c_split = 1; }       // F1 is only read by FF2: split form only
         launch_gemm(m, p, false, false);
         p = base_gemm(m, sg);
         p.A = ws.F1; p.lda = m->Fd; p.W = w.wf2; p.bias = w.bf2; p.C = ws.Y; p.ldc = D; p.N = D; p.Kc = m->Fd;
         p.resid = ws.Y; p.ldr = D;
-        use_x3(p, w.wf2x, X3_FF2);
-        launch_gemm(m, p, false, false, m->x3 ? STATS_PARTIALS : STATS_NONE);     // x3: the next block's Q|K|V scales its rows by these
+        if (ax3) { use_x3(p, w.wf2x); p.C2 = ws.YX; }                      // split copy of Y for the next block's Q|K|V
+        launch_gemm(m, p, false, false);
     }
     HIP_TRY(hipGetLastError());
     return HD_OK;

@@ -138,11 +138,11 @@ struct GemmP {
     // split-precision variant (gemm_x3_k): W as pre-tiled (hi, lo) fp16 planes scaled by a power of two, per segment at
     // + seg * wx_stride halfs; acc_scale = 2^-(weight shift + activation shift) undoes the scaling in the epilogue
     const uint16_t* Wx; long wx_stride; float acc_scale;
-    // ... and, for an A operand of unbounded magnitude (the raw residual stream), the LayerNorm slice partials its
-    // producer left: gemm_x3_k derives a per-row power-of-two scale from the row's rms so that the fp16 split can neither
-    // overflow nor lose its low part (never a prologue; ignored by gemm_k).  row_mul: the epilogue multiplies each row by
-    // rowst[row].y (gemm_x3_k puts rstd-of-a-folded-LayerNorm / row scale there).
-    const float2* xs_part; int xs_pw; long xs_rows; int row_mul;
+    // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
+    // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
+    // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
+    int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
+    float* C2;                        // epilogue: additional split copy of the output rows, row stride N (may be null)
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
     float* C; int ldc;                // [rows, N]
     int N, Kc, taps, dil;             // K = taps * Kc
@@ -203,7 +203,8 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // Shared GEMM epilogue: each wave transposes its accumulators through its own slice of LDS so that every lane owns
 // 4 consecutive columns of one row, then applies bias / activation / residual / dropout / addend on float4s, writes
 // with 16-B stores and (optionally) leaves the LayerNorm slice partials of the rows it wrote.
-// smem must hold 4 * 32 * (BN/WN + 4) + 4 * (BM/WM) * 2 floats and be free (all waves past their last LDS read).
+// smem must hold NW * 32 * (BN/WN + 4) + NW * (BM/WM) * 2 floats (NW = WM * WN waves) and be free (all waves past their
+// last LDS read).
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
@@ -211,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
-    constexpr int EPI_FLOATS = 4 * 32 * ES;
+    constexpr int EPI_FLOATS = WM * WN * 32 * ES;
     // the wave index is wave-uniform by construction; readfirstlane tells the compiler, so that everything derived
     // from it (row bases, buffer descriptors) lives in SGPRs and is advanced on the scalar unit
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -278,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
                 if (p.Wx) v *= p.acc_scale;                               // split-precision operands were scaled by powers of two
-                if (p.ln_fold || p.row_mul) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
+                if (p.ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
                 if (p.resid) v += rres[it];
@@ -306,11 +307,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     const_cast<float*>(p.extra) + (long)(rbase + g0) * p.lde, 0, BUF_MAX, 0x00020000);
                 v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, (int)(valid ? x_vo : BUF_OFF), 0, 0));
             }
-            {
+            if (!p.c_split) {
                 const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
                     p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
+            }
+            if (p.c_split || p.C2) {
+                // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const h16x4 hh = __builtin_convertvector(v, h16x4);
+                const h16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), h16x4);
+                float* base = p.c_split ? p.C : p.C2;
+                const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
+                const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
             }
             if (p.part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
@@ -673,7 +686,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
 
 
 // ------------------------------------------------------------------------------------------------
-// Split-precision GEMM (prototype behind HUDIFF_X3=1; the fp32 gemm_k stays the reference product path).
+// Split-precision GEMM (behind HUDIFF_X3=1; the fp32 gemm_k stays the reference product path).
 //
 // gfx950 multiplies fp32 operands on the matrix cores at 1/16 of the fp16 rate and has no TF32-like mode.  Here every
 // fp32 operand is written as hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significand bits; x - hi is exact in
@@ -681,59 +694,57 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
 // every fp16 x fp16 product is exact in fp32, the dropped a_lo w_lo term and the two roundings of the lo parts are each
 // <= 2^-22 relative -- the size of the rounding an fp32 accumulation makes at EVERY one of its K steps.  Three
 // 32-cycle MFMAs cover K = 16 for which the fp32 form needs eight 64-cycle ones.
-//   Weights are split once at hd_finalize (power-of-two scaled so that the lo parts stay normal fp16 numbers, laid out
-//   as the 128 x 32 tiles the blocks consume: plain 16-byte copies into LDS); activations are split while they are
-//   staged.  fp16 holds |x| < 65504 and loses the low part's accuracy below 2^-14, so an operand of unbounded magnitude
-//   (the raw residual stream in front of the Q|K|V and FF1 projections) is first multiplied by a per-row power of two taken
-//   from the row's rms (LayerNorm statistics its producer left: rms -> [2^6, 2^7), every element <= sqrt(K) rms < 2^12);
-//   operands that are bounded by construction (LayerNorm + activation outputs, attention outputs, ReLU(FF1)) are split
-//   as they are: below |x| = 2^-3 the low part is then exact only to 2^-25 ABSOLUTE, 1/2 ulp of an fp32 number near 1.
-//   The epilogue multiplies the accumulators by GemmP::acc_scale (weights) and the inverse row scale and is otherwise the
-//   fp32 kernel's own (bias, activation, residual, dropout, addend, LayerNorm partials, folded LayerNorm).
-// Shapes: Kc % 32 == 0, N % 128 == 0, no A prologue (LayerNorm folded or applied in place), operands < 2 GiB.
+//   Weights are split once at hd_finalize (power-of-two scaled so that the lo parts stay normal fp16 numbers) and laid
+//   out as the 128 x 32 LDS tile images the blocks consume.  Activations arrive ALREADY split ("X16" rows, see GemmP):
+//   whoever produces an operand of this kernel -- ln_apply_k, attn_k, a GEMM epilogue -- converts each element once,
+//   instead of every consumer block converting it again for each of its N tiles.  Activations are not scaled: fp16 holds
+//   |x| < 65504 (far beyond any LayerNorm-ed network's residual stream) and below |x| = 2^-3 the low part is exact to
+//   2^-25 ABSOLUTE, half an ulp of an fp32 number near 1.  The epilogue multiplies the accumulators by GemmP::acc_scale
+//   and is otherwise the fp32 kernel's own (bias, activation, residual, dropout, addend, LayerNorm partials, folded
+//   LayerNorm, fp32 and / or split output).
+// Shapes: Kc % 32 == 0, N % 128 == 0, no A prologue (LayerNorm folded or applied by ln_apply_k), operands < 2 GiB.
+//
+// K loop (k tile = 32): both operand tiles of k tile kt+1 travel global -> LDS by DMA (buffer_load ... lds: no registers,
+// no conversion, no ds_write) into the other of two LDS stages while tile kt is multiplied; one barrier per tile.  Tile
+// rows are 64 B (32 halfs) with the 16-byte chunks XOR-swizzled by (row >> 2) & 3 -- baked into the weight images at
+// hd_finalize, applied to the A rows by the lane -> chunk assignment of the DMA -- so that every ds_read_b128 of a
+// fragment is bank-conflict free without padding.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32;
-constexpr int X3_LDK = X3_BK + 8;                  // LDS row stride in halfs (80 B: 16-B aligned, conflict-free ds_read_b128)
-constexpr int X3_PLANE = X3_BM * X3_LDK;           // halfs per (128 x 32) plane in LDS
-constexpr int X3_TILE_HALFS = 2 * X3_BN * X3_BK;   // one pre-tiled weight tile in global memory: hi[128][32] then lo[128][32]
-constexpr int X3_ROW_RMS_EXP = 6;                  // per-row scaling brings the row's rms into [2^6, 2^7)
-
-// There is no A prologue: where the fp32 path normalises the operand while staging it (ByteNet PFF1 / PFF3), the
-// split-precision path normalises it once with ln_apply_k and multiplies the result.
-// K loop (k tile = 32): the weight tile of k tile kt+1 travels global -> LDS by DMA (buffer_load ... lds, no registers, no
-// ds_write) into the other of two LDS buffers while tile kt is multiplied; its rows are 64 B with the 16-byte chunks
-// XOR-swizzled by (n >> 2) & 3 -- baked into the global tile image at hd_finalize -- so that the ds_read_b128 of a fragment
-// is conflict-free without padding.  The fp32 A rows are fetched into registers TWO tiles ahead (two register sets, the loop
-// is unrolled by two: nkt must be even), split into (hi, lo) after the MFMAs of the current tile and written to the single
-// A buffer between the two barriers of a tile.
-constexpr int X3_WTILE_BYTES = X3_TILE_HALFS * 2;  // 16 KiB
+constexpr int X3_TILE_HALFS = 2 * X3_BN * X3_BK;   // one operand tile image: hi[128][32] then lo[128][32]
+constexpr int X3_TILE_BYTES = X3_TILE_HALFS * 2;   // 16 KiB
 // Block barrier that waits for this wave's LDS instructions only (lgkmcnt(0)): __syncthreads() -- and any fence the
-// compiler can see -- would also drain every outstanding vector-memory instruction at each of the two barriers of a tile,
-// i.e. the A rows prefetched two tiles ahead and the weight DMA in flight.  The DMA (a vector-memory instruction that
-// writes LDS) is waited for explicitly with s_waitcnt vmcnt where its data is needed; the empty asm statements keep the
-// compiler from moving LDS accesses across the barrier.
+// compiler can see -- would drain every outstanding vector-memory instruction as well.  The operand DMA (vector-memory
+// instructions that write LDS) is waited for explicitly with s_waitcnt vmcnt; the empty asm statements keep the compiler
+// from moving LDS accesses across the barrier.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-template <bool CONV>
-__global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
-    constexpr int BM = X3_BM, BN = X3_BN, BK = X3_BK, WM = 2, WN = 2;
+
+// Tile shapes.  The loop is bound by the rate at which a CU can pull operand tiles through its vector L1 into LDS
+// (~15 B / clk / CU measured: 128 x 128 tiles load 32 KiB per 1.05 MFLOP and stop at ~260 TFLOP/s-equivalent whatever the
+// pipelining), so the big launches use 256 x 256 tiles (8 waves, wave tile 128 x 64: twice the flops per byte) where N
+// allows, 256 x 128 where it does not, and 128 x 128 only for launches too small to fill the chip with larger tiles.
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_k(const GemmP p) {
+    constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
-    constexpr int EPI_FLOATS = 4 * 32 * ES, PART_FLOATS = 4 * WTM * 2;
-    constexpr int A_FLOATS = 2 * X3_PLANE / 2;                    // A hi + lo planes, padded rows
-    constexpr int LOOP_FLOATS = A_FLOATS + 2 * X3_WTILE_BYTES / 4;   // + two weight tile buffers
+    constexpr int EPI_FLOATS = NW * 32 * ES, PART_FLOATS = NW * WTM * 2;
+    constexpr int A_BYTES = 2 * BM * 64, W_BYTES = 2 * BN * 64;         // (hi, lo) images of BM / BN rows x 32 halfs
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int LOOP_FLOATS = 2 * STAGE_BYTES / 4;                  // two stages
     constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
+    constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
+    static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0, "tile / wave split");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
-    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
-    _Float16* Al = Ah + X3_PLANE;
-    char* Wb = reinterpret_cast<char*>(smem + A_FLOATS);          // buffer b at Wb + b * X3_WTILE_BYTES: hi plane, then lo plane
+    char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A hi, A lo, W hi, W lo
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -751,87 +762,68 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
     const int m0 = bx * BM, n0 = by * BN;
     const int Kc = p.Kc;
     const int nkt_tap = Kc / BK;
-    const int nkt = nkt_tap * p.taps;                  // even (host-checked)
+    const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
-    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * nkt * X3_TILE_HALFS;
+    // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
+    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
 
-    // per row of the tile: (power-of-two scale applied to the A row before the split, factor the epilogue multiplies the
-    // row by = rstd of a folded LayerNorm / that scale)
-    float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
-    const bool row_scaled = p.ln_fold || p.xs_part;
-    if (row_scaled) {
-        for (int r = tid; r < BM; r += 256) {
+    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
+        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += NT) {
             const int lrow = m0 + r;
-            const long grow = lrow < seg_rows ? (long)rbase + lrow : (long)rbase;
-            const float2 st = p.ln_fold ? gemm_row_stat(p, grow) : merge_row_stat(p.xs_part, p.xs_pw, p.xs_rows, Kc, grow);
-            const float ms = fmaxf(1.0f / (st.y * st.y) - 1e-5f, 0.f) + st.x * st.x;      // mean square of the row
-            int e = (int)((__float_as_uint(ms) >> 23) & 0xff) - 127;                        // floor(log2(ms)), ms normal or 0
-            e = ms > 0.f ? (e >> 1) : 0;                                                    // floor(log2(rms)) (arithmetic shift)
-            const int k = min(max(X3_ROW_RMS_EXP - e, -60), 60);
-            const float sc = __uint_as_float((uint32_t)(127 + k) << 23), inv = __uint_as_float((uint32_t)(127 - k) << 23);
-            rowst[r] = make_float2(sc, (p.ln_fold ? st.y : 1.0f) * inv);
+            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
         }
-        __syncthreads();
+        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
     }
-    // A staging: 128 rows x 8 float4 per k tile; thread -> k quad tid % 8, rows tid / 8 + 32 i
+    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
+    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
+    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
     constexpr uint32_t BUF_OOB = 0x80000000u;
-    const int a_kq = tid & 7;
-    int a_pos[4];
-    long a_row[4];
-    bool a_ok[4];
-    uint32_t t_boff[4];
+    int a_pos[A_PIECES];
+    long a_row[A_PIECES];
+    bool a_ok[A_PIECES];
+    uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int lrow = m0 + (tid >> 3) + 32 * i;
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int piece = NW * i + wave;                                 // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
+        const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
+        const int lrow = m0 + r;
         a_ok[i] = lrow < seg_rows;
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
-        t_boff[i] = a_ok[i] ? (uint32_t)((a_row[i] * p.lda + 4 * a_kq) * 4) : BUF_OOB;
+        a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
+        a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
     }
-    float a_sc[4] = {1.f, 1.f, 1.f, 1.f};
-    if (row_scaled) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_sc[i] = rowst[(tid >> 3) + 32 * i].x;
+    for (int i = 0; i < W_PIECES; ++i) {
+        const int piece = NW * i + wave;                                 // LDS image: hi plane of all BN rows, then lo plane
+        const int plane = piece / (BN / 16), rg = piece % (BN / 16);   // row group of 16 rows
+        const int t128 = rg / 8, rg8 = rg % 8;                           // which 128-column tile, row group within it
+        w_vo[i] = (uint32_t)(t128 * nkt * X3_TILE_BYTES + plane * (X3_TILE_BYTES / 2) + rg8 * 1024 + lane * 16);
     }
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, nkt * X3_WTILE_BYTES, 0x00020000);
-    auto fetch_a = [&](int kt, f32x4 (&ra)[4]) {
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    auto dma = [&](int kt, int st) {
         const int tap = CONV ? kt / nkt_tap : 0;
         const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
         if (CONV && kk0 == 0) {                        // first k tile of a tap: row shift + zero padding at the chain ends
             const int shift = (tap - half) * p.dil;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < A_PIECES; ++i) {
                 const int sp = a_pos[i] + shift;
                 const bool v = a_ok[i] && sp >= 0 && sp < Lc;
-                t_boff[i] = v ? (uint32_t)(((a_row[i] + shift) * p.lda + 4 * a_kq) * 4) : BUF_OOB;
+                a_vo[i] = v ? (uint32_t)((a_row[i] + shift) * p.lda * 4) + a_in[i] : BUF_OOB;
             }
         }
+        char* dst = St + st * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)t_boff[i], kk0 * 4, 0));
-    };
-    // weight tile kt -> LDS buffer `buf`: each wave copies 4 x 1 KiB (lane l -> 16 bytes at piece base + 16 l), linear image
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    auto dma_w = [&](int kt, int buf) {
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], kk0 * 2, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = i * 4 + wave;                                  // 16 pieces of 1 KiB
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(Wb + buf * X3_WTILE_BYTES + piece * 1024), 16,
-                                                 piece * 1024 + lane * 16, kt * X3_WTILE_BYTES, 0, 0);
-        }
-    };
-    auto commit_a = [&](const f32x4 (&ra)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 x = ra[i] * a_sc[i];
-            const f16x4 h = __builtin_convertvector(x, f16x4);
-            const f32x4 r = x - __builtin_convertvector(h, f32x4);       // exact in fp32
-            const f16x4 l = __builtin_convertvector(r, f16x4);
-            const int off = ((tid >> 3) + 32 * i) * X3_LDK + 4 * a_kq;
-            *reinterpret_cast<f16x4*>(Ah + off) = h;
-            *reinterpret_cast<f16x4*>(Al + off) = l;
-        }
+        for (int i = 0; i < W_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(dst + A_BYTES + (NW * i + wave) * 1024), 16, (int)w_vo[i],
+                                                     kt * X3_TILE_BYTES, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -842,30 +834,28 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int afrag = (lane & 31) * X3_LDK + 8 * (lane >> 5);           // row lane & 31, k octet lane >> 5 of a 16-deep k step
-    const _Float16* Aph = Ah + wm * WTM * X3_LDK + afrag;
-    const _Float16* Apl = Al + wm * WTM * X3_LDK + afrag;
-    // weight fragment: row n = wn * 64 + 32 j + (lane & 31) at n * 64 bytes, chunk (2 ks + g) stored at slot chunk ^ ((n >> 2) & 3)
-    const int wf = (lane >> 2) & 3, wg = lane >> 5;
-    const int wrow = (wn * WTN + (lane & 31)) * 64;
-    const int woff0 = wrow + (((0 + wg) ^ wf) << 4), woff1 = wrow + (((2 + wg) ^ wf) << 4);
-    auto mma = [&](int buf) {
-        const char* Wt = Wb + buf * X3_WTILE_BYTES;
+    // fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
+    // chunk ^ ((r >> 2) & 3); the wave part and 32 t do not touch bits 2..3 of r
+    const int fsw = (lane >> 2) & 3, fg = lane >> 5;
+    const int foff0 = (lane & 31) * 64 + (((0 + fg) ^ fsw) << 4), foff1 = (lane & 31) * 64 + (((2 + fg) ^ fsw) << 4);
+    auto mma = [&](int st) {
+        const char* At = St + st * STAGE_BYTES + wm * WTM * 64;
+        const char* Wt = St + st * STAGE_BYTES + A_BYTES + wn * WTN * 64;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const int o = ks ? foff1 : foff0;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(Aph + 32 * i * X3_LDK + 16 * ks);
-                al[i] = *reinterpret_cast<const f16x8*>(Apl + 32 * i * X3_LDK + 16 * ks);
+                ah[i] = *reinterpret_cast<const f16x8*>(At + o + 32 * 64 * i);
+                al[i] = *reinterpret_cast<const f16x8*>(At + A_BYTES / 2 + o + 32 * 64 * i);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int o = (ks ? woff1 : woff0) + 32 * 64 * j;
-                bh[j] = *reinterpret_cast<const f16x8*>(Wt + o);
-                bl[j] = *reinterpret_cast<const f16x8*>(Wt + X3_WTILE_BYTES / 2 + o);
+                bh[j] = *reinterpret_cast<const f16x8*>(Wt + o + 32 * 64 * j);
+                bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + o + 32 * 64 * j);
             }
-            // the two cross terms first, the leading term last: four independent accumulators per term
+            // the two cross terms first, the leading term last: TM x TN independent accumulators per term
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -880,32 +870,16 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    // one k tile: `cur` holds A(kt+1) (fetched a tile ago), `nxt` receives A(kt+2); weights of tile kt sit in buffer wb
-    auto step = [&](int kt, f32x4 (&cur)[4], f32x4 (&nxt)[4], int wb) {
-        const bool more = kt + 1 < nkt, more2 = kt + 2 < nkt;
-        if (more) dma_w(kt + 1, wb ^ 1);               // that buffer was last read in tile kt-1: every wave is past its barrier
-        if (more2) fetch_a(kt + 2, nxt);
-        mma(wb);
-        lds_barrier();                                 // every wave is done reading the A planes of this tile
-        if (more) commit_a(cur);
-        // the weight DMA of tile kt+1 must have landed before anyone reads it: everything issued before the (up to) four
-        // A loads of tile kt+2 has to be back
-        if (more2) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
-        lds_barrier();
-    };
-    f32x4 ra0[4], ra1[4];
-    fetch_a(0, ra0);
-    dma_w(0, 0);
-    if (nkt > 1) fetch_a(1, ra1);
-    commit_a(ra0);
-    if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA has landed
     lds_barrier();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(kt, ra1, ra0, 0);
-        step(kt + 1, ra0, ra1, 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage (kt+1) & 1 was read in tile kt-1; every wave is past the barrier that ended that tile
+        if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
+        mma(kt & 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // this wave's part of the next tile is in LDS ...
+        lds_barrier();                                 // ... and everybody's is; everybody is done reading this tile
     }
-    __syncthreads();
     gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
@@ -915,11 +889,13 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_k(const GemmP p) {
 // for each of its 7 taps and each of its N tiles.  One wave per row; gamma / beta are per chain segment.
 // ------------------------------------------------------------------------------------------------
 // `stats` (ready-made (mean, rstd) per row) may replace the partials; Y / ldy: output rows (== X, ldx for in place).
+// split_out: the output row is written in split form (C fp16 high parts, then C fp16 low parts; ldy == C) for gemm_x3_k.
+// In place this overwrites bytes other lanes still have to read, so the whole row is read before anything is written.
 __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ part, int pw, int C, int rows,
                                                    const float* X, int ldx, float* Y, int ldy, const float2* __restrict__ stats,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, int k_stride, int seg1_row0,
-                                                   int act) {
+                                                   int act, int split_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float mean, rstd;
@@ -935,6 +911,30 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
     const float* b = beta + seg * k_stride;
     const float* x = X + (long)row * ldx;
     float* y = Y + (long)row * ldy;
+    if (split_out) {                                   // C <= 1024
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < C) v[j] = *reinterpret_cast<const f32x4*>(x + c);
+        }
+        _Float16* yh = reinterpret_cast<_Float16*>(y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < C) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+                f32x4 w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = act_f((v[j][k] - mean) * rstd * gv[k] + bv[k], act);
+                const f16x4 hh = __builtin_convertvector(w, f16x4);
+                const f16x4 ll = __builtin_convertvector(w - __builtin_convertvector(hh, f32x4), f16x4);
+                *reinterpret_cast<f16x4*>(yh + c) = hh;
+                *reinterpret_cast<f16x4*>(yh + C + c) = ll;
+            }
+        }
+        return;
+    }
     for (int c = lane * 4; c < C; c += 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c), bv = *reinterpret_cast<const f32x4*>(b + c);
@@ -1129,7 +1129,7 @@ template <int NKT, int ABL = 0>
 __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
                                                           const float* __restrict__ rope_cos,
                                                           const float* __restrict__ rope_sin,
-                                                          float* __restrict__ O, int ldo, int nhead, Segs sg) {
+                                                          float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VS = att_vs(NKT);
     const int L = sg.L;
@@ -1300,7 +1300,16 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 o = oacc[dt];
                 o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
-                *reinterpret_cast<f32x4*>(O + qrow * ldo + h * ATT_HD + 16 * dt + 4 * g) = o;
+                const int col = h * ATT_HD + 16 * dt + 4 * g;
+                if (o_split) {                         // split rows for the out-projection's gemm_x3_k (ldo halfs hi, then lo)
+                    const f16x4 hh = __builtin_convertvector(o, f16x4);
+                    const f16x4 ll = __builtin_convertvector(o - __builtin_convertvector(hh, f32x4), f16x4);
+                    _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
+                    *reinterpret_cast<f16x4*>(orow + col) = hh;
+                    *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
+                } else {
+                    *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
+                }
             }
         }
     }
