@@ -1316,6 +1316,218 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision attention (HUDIFF_X3=1, L <= 304, head dim 64): the structure of attn_k -- one block per (sequence,
+// head), K and V resident in LDS, S^T = K Q^T in accumulators so that the softmax is lane-local and exp(S) is directly
+// the B operand of O^T = V^T P^T -- with every product as three fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulate):
+//   S  ~= K_hi Q_hi + K_hi Q_lo + K_lo Q_hi        O ~= V_hi P_hi + V_hi P_lo + V_lo P_hi
+// K (rotated) and V are split once while they are staged (the same bytes in LDS as fp32: hi + lo halfs); Q per query
+// tile and P per 32-key step are split in registers.  Each 16x16x32 MFMA covers K = 32 in 16 cycles where the fp32 form
+// needs eight 32-cycle 16x16x4 ones.
+//   K planes  [304 keys][64 halfs]: 128-byte rows, 16-byte chunks XOR-swizzled by (key >> 1) & 7 (conflict-free fragments)
+//   V^T planes [64 d][320 keys]   : key order inside every 32-key block permuted to the order the S^T accumulators hold
+//                                   P in -- chunk 4 t + g = keys {32 t + 4 g + r, 32 t + 16 + 4 g + r}, r = 0..3 -- so P
+//                                   goes from the softmax registers into the MFMA without a shuffle; same swizzle by d.
+// ------------------------------------------------------------------------------------------------
+constexpr int AX_KT = 19;                          // 16-key tiles (L <= 304)
+constexpr int AX_KROWS = 16 * AX_KT;               // 304
+constexpr int AX_VKEYS = 320;                      // V^T row length (keys), a multiple of 32
+constexpr int AX_KPLANE = AX_KROWS * 128, AX_VPLANE = 64 * AX_VKEYS * 2;        // bytes
+constexpr int AX_SMEM = 2 * AX_KPLANE + 2 * AX_VPLANE;                           // 159 744 B
+
+__global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
+                                                            const float* __restrict__ rope_cos,
+                                                            const float* __restrict__ rope_sin,
+                                                            float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
+    extern __shared__ __attribute__((aligned(16))) char axs[];
+    char* Kh = axs;
+    char* Kl = axs + AX_KPLANE;
+    char* Vh = axs + 2 * AX_KPLANE;
+    char* Vl = Vh + AX_VPLANE;
+    const int L = sg.L;
+    const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
+
+    // ---- stage K: rotate, split, swizzled 8-byte writes (keys >= L are zero rows) -------------------------------------
+    {
+        constexpr int NST = (AX_KROWS * 16 + ATT_THREADS - 1) / ATT_THREADS;
+        f32x4 kb[NST];
+        float2 cb[NST], sb[NST];
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + ATT_THREADS * k;
+            const int key = min(idx >> 4, L - 1), c4 = (idx & 15) * 4;
+            kb[k] = *reinterpret_cast<const f32x4*>(QKV + (long)sg.row(b, key) * ldq + koff + c4);
+            cb[k] = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
+            sb[k] = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + ATT_THREADS * k;
+            if (idx < AX_KROWS * 16) {
+                const int key = idx >> 4, c4 = (idx & 15) * 4;
+                const f32x4 kv = kb[k];
+                f32x4 kr;
+                kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
+                kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
+                if (key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f16x4 hh = __builtin_convertvector(kr, f16x4);
+                const f16x4 ll = __builtin_convertvector(kr - __builtin_convertvector(hh, f32x4), f16x4);
+                const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
+                *reinterpret_cast<f16x4*>(Kh + off) = hh;
+                *reinterpret_cast<f16x4*>(Kl + off) = ll;
+            }
+        }
+    }
+    // ---- stage V^T: a wave takes 8-key chunks, lane = d; 8 row loads (256 B each), two 16-byte writes ------------------
+    {
+        constexpr int NCH = AX_VKEYS / 8 / (ATT_THREADS / 64);       // 5 chunks per wave
+        float vv[NCH][8];
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int c = wave + (ATT_THREADS / 64) * cc;            // chunk 4 t + g
+            const int t = c >> 2, g = c & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
+                vv[cc][j] = QKV[(long)sg.row(b, min(key, L - 1)) * ldq + voff + lane];
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int c = wave + (ATT_THREADS / 64) * cc;
+            const int t = c >> 2, g = c & 3;
+            f16x8 hh, ll;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
+                const float x = key < L ? vv[cc][j] : 0.f;
+                const _Float16 xh = (_Float16)x;
+                hh[j] = xh; ll[j] = (_Float16)(x - (float)xh);
+            }
+            const int off = lane * (AX_VKEYS * 2) + (((c & ~7) | ((c & 7) ^ ((lane >> 1) & 7))) << 4);
+            *reinterpret_cast<f16x8*>(Vh + off) = hh;
+            *reinterpret_cast<f16x8*>(Vl + off) = ll;
+        }
+    }
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const int sw = (qi >> 1) & 7;                      // swizzle of this lane's K row / V^T row (rows 16 kt + qi, 16 dt + qi)
+    const int nqt = (L + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
+        const int q = qt * 16 + qi;
+        const int qc = q < L ? q : L - 1;
+        const long qrow = sg.row(b, qc);
+        // Q fragment (B operand): lane holds Q[q][32 ks + 8 g + 0..7], rotated, pre-scaled by log2(e) / 8, split
+        f16x8 qh[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c4 = 32 * ks + 8 * g + 4 * hf;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
+                const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
+                const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
+                constexpr float QS = 0.125f * 1.44269504088896340736f;
+                f32x4 r;
+                r[0] = (v[0] * cs.x - v[1] * sn.x) * QS; r[1] = (v[0] * sn.x + v[1] * cs.x) * QS;
+                r[2] = (v[2] * cs.y - v[3] * sn.y) * QS; r[3] = (v[2] * sn.y + v[3] * cs.y) * QS;
+                const f16x4 hh = __builtin_convertvector(r, f16x4);
+                const f16x4 ll = __builtin_convertvector(r - __builtin_convertvector(hh, f32x4), f16x4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qh[ks][4 * hf + e] = hh[e]; ql[ks][4 * hf + e] = ll[e]; }
+            }
+        }
+        // S^T tiles (keys x queries), two key tiles per pass: two independent accumulator chains
+        f32x4 st[AX_KT + 1];
+#pragma unroll
+        for (int kt = 0; kt < AX_KT; kt += 2) {
+            const bool two = kt + 1 < AX_KT;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const int r0 = (kt * 16 + qi) * 128, r1 = ((kt + 1) * 16 + qi) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((4 * ks + g) ^ sw) << 4;
+                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(Kh + r0 + co), kl0 = *reinterpret_cast<const f16x8*>(Kl + r0 + co);
+                f16x8 kh1 = kh0, kl1 = kl0;
+                if (two) { kh1 = *reinterpret_cast<const f16x8*>(Kh + r1 + co); kl1 = *reinterpret_cast<const f16x8*>(Kl + r1 + co); }
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[ks], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[ks], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, ql[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, qh[ks], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, qh[ks], acc1, 0, 0, 0);
+            }
+            st[kt] = acc0;
+            if (two) st[kt + 1] = acc1;
+            __builtin_amdgcn_sched_barrier(0);   // keep later tiles' LDS reads from being hoisted (VGPR pressure)
+        }
+        st[AX_KT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // softmax over keys (rows of S^T); this lane owns keys 16 kt + 4 g + r.  Scores live in the log2 domain.
+        float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < AX_KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;       // compile-time false except in the last tiles
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+        for (int kt = 0; kt < AX_KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx); st[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // O^T[d, q] = sum_key V^T[d, key] P^T[key, q], 32 keys per step: P of two S^T tiles is this lane's B operand as it is
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < (AX_KT + 1) / 2; ++t) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = st[2 * t + (j >> 2)][j & 3];
+                const _Float16 xh = (_Float16)x;
+                ph[j] = xh; pl[j] = (_Float16)(x - (float)xh);
+            }
+            const int c = 4 * t + g;
+            const int co = ((c & ~7) | ((c & 7) ^ sw)) << 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int ro = (16 * dt + qi) * (AX_VKEYS * 2) + co;
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + ro), vl = *reinterpret_cast<const f16x8*>(Vl + ro);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 o = oacc[dt];
+                o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+                const int col = h * ATT_HD + 16 * dt + 4 * g;
+                if (o_split) {
+                    const f16x4 hh = __builtin_convertvector(o, f16x4);
+                    const f16x4 ll = __builtin_convertvector(o - __builtin_convertvector(hh, f32x4), f16x4);
+                    _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
+                    *reinterpret_cast<f16x4*>(orow + col) = hh;
+                    *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
+                } else {
+                    *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pruned last attention block (sampling only).  After the last SelfAttBlock only the row of the slot visited
 // at this step feeds the decoder (sample.py:508-513), so for that block the second attention's query side,
 // the out-projection and the feed-forward are evaluated for ONE row per sequence:
