@@ -317,7 +317,7 @@ def main():
     tokens = model.sample_end()
     split = None
     if rank == 0 and world == 1 and args.max_t == 0 and not args.no_split_line and os.environ.get("HUDIFF_X3", "0") in ("", "0"):
-        ref_rows = min(B, 32)
+        ref_rows = min(B, 64)          # enough activation rows (>= 8192) for the big-launch kernels on both models
         ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
         ref_logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023,
                            row0=rank * B, step=0)

@@ -804,6 +804,8 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;
         q.sg = run;
+        static const int abl = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e ? atoi(e) : 0; }();
+        q.x3_abl = abl;
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
         // tile shape: the largest whose launch still fills the chip (the loop is bound by bytes pulled into LDS per flop)
         static const int force = [] { const char* e = getenv("HUDIFF_X3_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 / 512 (= 256 x 256)

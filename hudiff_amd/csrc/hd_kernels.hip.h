@@ -141,6 +141,7 @@ struct GemmP {
     // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
     // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
     // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
+    int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tile
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
     float* C2;                        // epilogue: additional split copy of the output rows, row stride N (may be null)
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
@@ -875,8 +876,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_
     lds_barrier();
     for (int kt = 0; kt < nkt; ++kt) {
         // stage (kt+1) & 1 was read in tile kt-1; every wave is past the barrier that ended that tile
-        if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
-        mma(kt & 1);
+        if (kt + 1 < nkt && p.x3_abl != 2) dma(kt + 1, (kt + 1) & 1);
+        if (p.x3_abl != 1) mma(kt & 1);
         __builtin_amdgcn_s_waitcnt(0x0F70);            // this wave's part of the next tile is in LDS ...
         lds_barrier();                                 // ... and everybody's is; everybody is done reading this tile
     }

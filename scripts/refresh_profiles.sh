@@ -44,6 +44,14 @@ json.dump({"git_head": "$HEAD",
 print(dict(tot))
 PY
 $R/scripts/valu_profile.sh > $OUT/valu_vs_mfma.txt 2>&1
+# ---- split-precision prototype (HUDIFF_X3=1): per-kernel times of the same 6-step run, error / token agreement report
+HUDIFF_X3=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3stats -o t -- $CMD > $OUT/x3stats.log 2>&1
+cp $(find $OUT/x3stats -name "*kernel_stats.csv" | head -1) $OUT/x3_ab256_maxt6_lanes1_kernel_stats.csv
+HUDIFF_X3=1 timeout 400 rocprofv3 --kernel-trace -d $OUT/x3trace -o t -- $CMD > $OUT/x3trace.log 2>&1
+python $R/scripts/rocpd_summary.py $(find $OUT/x3trace -name "*.db" | head -1) --by-grid > $OUT/x3_ab256_maxt6_lanes1_by_grid.txt
+python $R/scripts/x3_eval.py ab 2>/dev/null | tail -1 > $OUT/x3_eval_ab.json
+python $R/scripts/x3_eval.py nb 2>/dev/null | tail -1 > $OUT/x3_eval_nb.json
+rm -rf $OUT/x3stats $OUT/x3trace
 echo "$HEAD" > $OUT/GIT_HEAD
 rm -rf $OUT/stats $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_* $OUT/pmc_TCC_*
 ls -la $OUT
