@@ -23,6 +23,7 @@ using namespace hd;
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static thread_local std::string g_launch_err;       // set by a launch helper that refused to launch (checked by forward_body)
 
 static HdStatus fail(HdStatus st, const char* fmt, ...) {
     char buf[1024];
@@ -718,7 +719,8 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
 // Split-precision launches (gemm_x3_k): the A operand must already be in split form, so the decision is taken by the
 // caller BEFORE it asks the producer for split rows -- x3_use() holds every condition launch_gemm checks again.
 static bool x3_use(const HdModel* m, const Segs& sg, const X3W& x) {
-    return m->x3 && x.w && (long)sg.B * sg.L >= 8192 && (long)sg.B * sg.L * 1536 * 4 < (1L << 31);
+    const long rows = (long)sg.B * sg.L, widest = 3L * m->A > m->D ? 3L * m->A : m->D;       // 32-bit byte offsets in every operand
+    return m->x3 && x.w && rows >= 8192 && rows * widest * 4 < (1L << 31);
 }
 static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
@@ -796,9 +798,12 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     if (p.Wx) {
         const int xpro = (!p.ln_fold && (p.stats || p.spart)) ? 1 : 0;
         if (!(big && fast_ok && !xpro && p.Kc % X3_BK == 0 && p.N % X3_BN == 0 && (long)p.taps * p.Kc * X3_BN * 4 < (1L << 31))) {
-            // cannot happen for shapes x3_use() admits; never fall back silently on an operand that is not fp32
-            fprintf(stderr, "libhudiff_hip: split-precision launch with an ineligible shape (rows %ld Kc %d N %d taps %d)\n", rows, p.Kc, p.N, p.taps);
-            abort();
+            // cannot happen for shapes x3_use() admits; never run an operand that is not fp32 through an fp32 kernel:
+            // nothing is launched and the forward reports the error (forward_body)
+            char buf[160];
+            snprintf(buf, sizeof(buf), "split-precision launch with an ineligible shape (rows %ld Kc %d N %d taps %d)", rows, p.Kc, p.N, p.taps);
+            g_launch_err = buf;
+            return;
         }
         Segs run = p.sg;
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
@@ -1105,6 +1110,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         launch_gemm(m, p, false, false);
     }
     HIP_TRY(hipGetLastError());
+    if (!g_launch_err.empty()) { const std::string e = g_launch_err; g_launch_err.clear(); return fail(HD_ERR_STATE, "%s", e.c_str()); }
     return HD_OK;
 }
 
