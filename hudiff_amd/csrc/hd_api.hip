@@ -812,28 +812,27 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         static const int abl = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e ? atoi(e) : 0; }();
         q.x3_abl = abl;
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
-        // tile shape: the largest whose launch still fills the chip (the loop is bound by bytes pulled into LDS per flop)
-        static const int force = [] { const char* e = getenv("HUDIFF_X3_TILE"); return e ? atoi(e) : 0; }();   // 128 / 256 / 512 (= 256 x 256)
+        // tile shape / pipeline depth, by measurement: 256 x 256 tiles (two stages, one 8-wave block per CU)
+        // for the widest output (Q|K|V, N = 1536: 621 vs 650 us), two stages of 128 x 128 tiles (two blocks per CU) elsewhere; three
+        // stages of 256 x 128 tiles were no faster anywhere (640 us).  HUDIFF_X3_TILE forces 128 / 256 (x 128, three stages) / 512 (= 256 x 256)
+        static const int force = [] { const char* e = getenv("HUDIFF_X3_TILE"); return e ? atoi(e) : 0; }();
         const long t256 = (rows0 + 255) / 256 + (rows1 + 255) / 256;
-        // measured (profiles/r02): 256 x 256 tiles pay off for the widest output only (Q|K|V, N = 1536: 583 vs 650 us); for
-        // N <= 768 the one-block-per-CU kernels lose more to barrier stalls than they save in operand traffic
-        int shape = 128;
-        if (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) shape = 512;
-        if (force == 128 || (force == 256 && shape == 512) || (force == 512 && q.N % 256 == 0)) shape = force;
+        int shape = (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) ? 512 : 128;
+        if (force == 128 || force == 256 || (force == 512 && q.N % 256 == 0)) shape = force;
         const int bm = shape == 128 ? 128 : 256, bn = shape == 512 ? 256 : 128;
         q.tiles0 = (rows0 + bm - 1) / bm;
         q.tiles_m = q.tiles0 + (rows1 + bm - 1) / bm;
         q.tiles_n = q.N / bn;
         dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n);
         if (shape == 512) {
-            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, true>), grid, dim3(512), 0, st, q);
-            else hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, false>), grid, dim3(512), 0, st, q);
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, true, 2>), grid, dim3(512), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, false, 2>), grid, dim3(512), 0, st, q);
         } else if (shape == 256) {
-            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, true>), grid, dim3(512), 0, st, q);
-            else hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, false>), grid, dim3(512), 0, st, q);
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, true, 3>), grid, dim3(512), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, false, 3>), grid, dim3(512), 0, st, q);
         } else {
-            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true>), grid, dim3(256), 0, st, q);
-            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false>), grid, dim3(256), 0, st, q);
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);
         }
     } else
     if (big && fast_ok && tiles128 < small_tiles) {

@@ -141,7 +141,8 @@ struct GemmP {
     // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
     // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
     // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
-    int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tile
+    int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tiles,
+                                      // 3 = neither (epilogue only), 4 = one LDS fragment read per k step
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
     float* C2;                        // epilogue: additional split copy of the output rows, row stride N (may be null)
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
@@ -731,15 +732,19 @@ __device__ __forceinline__ void lds_barrier() {
 // (~15 B / clk / CU measured: 128 x 128 tiles load 32 KiB per 1.05 MFLOP and stop at ~260 TFLOP/s-equivalent whatever the
 // pipelining), so the big launches use 256 x 256 tiles (8 waves, wave tile 128 x 64: twice the flops per byte) where N
 // allows, 256 x 128 where it does not, and 128 x 128 only for launches too small to fill the chip with larger tiles.
-template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_k(const GemmP p) {
+// NS LDS stages: NS - 1 operand tiles are in flight while one is multiplied.  A tile's DMA round trip is ~1.5 us (3 000 cycles)
+// under load -- four times the MFMA time of a 128 x 128 x 32 tile -- so with two stages the loop is bound by that latency
+// (DMA-only ablation: 24 round trips per block); the big launches use three stages of 256 x 128 tiles (144 KB, one block of
+// eight waves per CU).
+template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 1) gemm_x3_k(const GemmP p) {
     constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
     constexpr int EPI_FLOATS = NW * 32 * ES, PART_FLOATS = NW * WTM * 2;
     constexpr int A_BYTES = 2 * BM * 64, W_BYTES = 2 * BN * 64;         // (hi, lo) images of BM / BN rows x 32 halfs
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int LOOP_FLOATS = 2 * STAGE_BYTES / 4;                  // two stages
+    constexpr int LOOP_FLOATS = NS * STAGE_BYTES / 4;
     constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
@@ -846,6 +851,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int o = ks ? foff1 : foff0;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            if (p.x3_abl == 4) {                       // probe: one fragment read per k step instead of 2 (TM + TN)
+                const f16x8 f = *reinterpret_cast<const f16x8*>(At + o);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { ah[i] = f; al[i] = f; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { bh[j] = f; bl[j] = f; }
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(At + o + 32 * 64 * i);
@@ -855,6 +867,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(Wt + o + 32 * 64 * j);
                 bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + o + 32 * 64 * j);
+            }
             }
             // the two cross terms first, the leading term last: TM x TN independent accumulators per term
 #pragma unroll
@@ -871,15 +884,27 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) gemm_x3_
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    dma(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the DMA has landed
+    // s_waitcnt vmcnt(n): this wave's DMA instructions except the n most recent have landed.  In the steady state the tiles
+    // issued after tile kt+1 are kt+2 .. kt+NS-1, i.e. (NS - 2) * (A_PIECES + W_PIECES) instructions.
+    constexpr int PER_TILE = A_PIECES + W_PIECES, KEEP = (NS - 2) * PER_TILE;
+    static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
+    constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nkt) dma(t, t);
+    if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
     lds_barrier();
+    int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage (kt+1) & 1 was read in tile kt-1; every wave is past the barrier that ended that tile
-        if (kt + 1 < nkt && p.x3_abl != 2) dma(kt + 1, (kt + 1) & 1);
-        if (p.x3_abl != 1) mma(kt & 1);
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // this wave's part of the next tile is in LDS ...
-        lds_barrier();                                 // ... and everybody's is; everybody is done reading this tile
+        const bool more = kt + NS - 1 < nkt;
+        // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
+        if (more && p.x3_abl != 2 && p.x3_abl != 3) dma(kt + NS - 1, st_in);
+        if (p.x3_abl != 1 && p.x3_abl != 3) mma(st);
+        // tile kt+1 must have landed before the next iteration reads it ...
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        lds_barrier();                                 // ... everybody's part of it; everybody is done reading tile kt
+        st_in = st;
+        st = st + 1 == NS ? 0 : st + 1;
     }
     gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
