@@ -1374,11 +1374,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
 
-    // ---- stage K: rotate, split, swizzled 8-byte writes (keys >= L are zero rows) -------------------------------------
+    // ---- stage K (rotate, split, swizzled 8-byte writes; keys >= L are zero rows) and V^T (a wave takes 8-key chunks,
+    //      lane = d: 8 row loads of 256 B each, two 16-byte writes).  Every global load of both is issued before the first
+    //      value is consumed: one exposed round trip per block instead of two.
     {
         constexpr int NST = (AX_KROWS * 16 + ATT_THREADS - 1) / ATT_THREADS;
+        constexpr int NCH = AX_VKEYS / 8 / (ATT_THREADS / 64);       // 5 chunks per wave
         f32x4 kb[NST];
         float2 cb[NST], sb[NST];
+        float vv[NCH][8];
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int idx = tid + ATT_THREADS * k;
@@ -1386,6 +1390,16 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
             kb[k] = *reinterpret_cast<const f32x4*>(QKV + (long)sg.row(b, key) * ldq + koff + c4);
             cb[k] = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
             sb[k] = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int c = wave + (ATT_THREADS / 64) * cc;            // chunk 4 t + g
+            const int t = c >> 2, g = c & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
+                vv[cc][j] = QKV[(long)sg.row(b, min(key, L - 1)) * ldq + voff + lane];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -1402,21 +1416,6 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
                 *reinterpret_cast<f16x4*>(Kh + off) = hh;
                 *reinterpret_cast<f16x4*>(Kl + off) = ll;
-            }
-        }
-    }
-    // ---- stage V^T: a wave takes 8-key chunks, lane = d; 8 row loads (256 B each), two 16-byte writes ------------------
-    {
-        constexpr int NCH = AX_VKEYS / 8 / (ATT_THREADS / 64);       // 5 chunks per wave
-        float vv[NCH][8];
-#pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-            const int c = wave + (ATT_THREADS / 64) * cc;            // chunk 4 t + g
-            const int t = c >> 2, g = c & 3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
-                vv[cc][j] = QKV[(long)sg.row(b, min(key, L - 1)) * ldq + voff + lane];
             }
         }
 #pragma unroll
