@@ -653,7 +653,10 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     }
     const size_t smem = (size_t)L * (ATT_KS + att_vs(L > 160 ? 19 : 10)) * sizeof(float);
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (m->x3) HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_SMEM));
+    if (m->x3) {
+        HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<19>::SMEM));
+        HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<10>::SMEM));
+    }
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
@@ -977,8 +980,10 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
     if (x3 && ax_on && m->L > 160 && m->L <= AX_KROWS)
-        hipLaunchKernelGGL(attn_x3_k, grid, dim3(ATT_THREADS), (size_t)AX_SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
-    else if (m->L > 160)
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<19>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
+    else if (x3 && ax_on && m->L <= 160) {
+        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
+    } else if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
     else
         hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);

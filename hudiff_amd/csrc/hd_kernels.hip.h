@@ -1354,22 +1354,38 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
 //                                   P in -- chunk 4 t + g = keys {32 t + 4 g + r, 32 t + 16 + 4 g + r}, r = 0..3 -- so P
 //                                   goes from the softmax registers into the MFMA without a shuffle; same swizzle by d.
 // ------------------------------------------------------------------------------------------------
-constexpr int AX_KT = 19;                          // 16-key tiles (L <= 304)
-constexpr int AX_KROWS = 16 * AX_KT;               // 304
-constexpr int AX_VKEYS = 320;                      // V^T row length (keys), a multiple of 32
-constexpr int AX_KPLANE = AX_KROWS * 128, AX_VPLANE = 64 * AX_VKEYS * 2;        // bytes
-constexpr int AX_SMEM = 2 * AX_KPLANE + 2 * AX_VPLANE;                           // 159 744 B
+// KT = 16-key tiles: 19 (L <= 304, the antibody model: 159 744 B of LDS, one block per CU) or 10 (L <= 160, the nanobody model:
+// 81 920 B, two blocks per CU).  The V^T rows are 64 KT' bytes (KT' = KT rounded up to even), i.e. 32 or 16 banks apart modulo the
+// 64 banks: the swizzle that spreads the 16 rows a fragment read touches is (d >> 1) & 7 over groups of 8 chunks, resp.
+// (d >> 2) & 3 over groups of 4.
+template <int KT> struct AxGeom {
+    static constexpr int KROWS = 16 * KT, VKEYS = 32 * ((KT + 1) / 2);
+    static constexpr int KPLANE = KROWS * 128, VPLANE = 64 * VKEYS * 2;             // bytes
+    static constexpr int SMEM = 2 * KPLANE + 2 * VPLANE;
+    static constexpr bool WIDE = (VKEYS * 2) % 256 == 128;                          // 640-byte rows (KT = 19); else 320 (KT = 10)
+    static_assert(WIDE || (VKEYS * 2) % 256 == 64, "V^T row stride must be 32 or 16 banks modulo 64");
+    __device__ static constexpr int vpos(int c, int d) {                            // chunk c of row d -> swizzled chunk position
+        return WIDE ? ((c & ~7) | ((c & 7) ^ ((d >> 1) & 7))) : ((c & ~3) | ((c & 3) ^ ((d >> 2) & 3)));
+    }
+};
+constexpr int AX_KROWS = AxGeom<19>::KROWS;        // longest sequence the kernel family covers
 
-__global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
+template <int KT>
+__global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
                                                             const float* __restrict__ rope_cos,
                                                             const float* __restrict__ rope_sin,
                                                             float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
+    typedef AxGeom<KT> G;
+    constexpr int AX_KT = KT, AX_KROWS = G::KROWS, AX_VKEYS = G::VKEYS, AX_KPLANE = G::KPLANE, AX_VPLANE = G::VPLANE;
+    // K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the nanobody model that is
+    // 79 872 B -- two blocks per CU with 4 KB to spare.  (With 160 zero-padded rows the block took 81 920 B, two blocks filled
+    // the CU's 163 840 B exactly, and blocks that started beside a running one produced wrong rows now and then.)
     extern __shared__ __attribute__((aligned(16))) char axs[];
-    char* Kh = axs;
-    char* Kl = axs + AX_KPLANE;
-    char* Vh = axs + 2 * AX_KPLANE;
-    char* Vl = Vh + AX_VPLANE;
     const int L = sg.L;
+    char* Kh = axs;
+    char* Kl = axs + L * 128;
+    char* Vh = axs + 2 * L * 128;
+    char* Vl = Vh + AX_VPLANE;
     const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
@@ -1379,7 +1395,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
     //      value is consumed: one exposed round trip per block instead of two.
     {
         constexpr int NST = (AX_KROWS * 16 + ATT_THREADS - 1) / ATT_THREADS;
-        constexpr int NCH = AX_VKEYS / 8 / (ATT_THREADS / 64);       // 5 chunks per wave
+        constexpr int NCHUNK = AX_VKEYS / 8;                          // 40 / 20 chunks of 8 keys
+        constexpr int NCH = (NCHUNK + ATT_THREADS / 64 - 1) / (ATT_THREADS / 64);
         f32x4 kb[NST];
         float2 cb[NST], sb[NST];
         float vv[NCH][8];
@@ -1393,7 +1410,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
         }
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) {
-            const int c = wave + (ATT_THREADS / 64) * cc;            // chunk 4 t + g
+            const int c = min(wave + (ATT_THREADS / 64) * cc, NCHUNK - 1);            // chunk 4 t + g
             const int t = c >> 2, g = c & 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1404,13 +1421,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int idx = tid + ATT_THREADS * k;
-            if (idx < AX_KROWS * 16) {
+            if (idx < L * 16) {
                 const int key = idx >> 4, c4 = (idx & 15) * 4;
                 const f32x4 kv = kb[k];
                 f32x4 kr;
                 kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
                 kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
-                if (key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};
                 const f16x4 hh = __builtin_convertvector(kr, f16x4);
                 const f16x4 ll = __builtin_convertvector(kr - __builtin_convertvector(hh, f32x4), f16x4);
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
@@ -1421,6 +1437,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) {
             const int c = wave + (ATT_THREADS / 64) * cc;
+            if (c >= NCHUNK) continue;
             const int t = c >> 2, g = c & 3;
             f16x8 hh, ll;
 #pragma unroll
@@ -1430,7 +1447,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
                 const _Float16 xh = (_Float16)x;
                 hh[j] = xh; ll[j] = (_Float16)(x - (float)xh);
             }
-            const int off = lane * (AX_VKEYS * 2) + (((c & ~7) | ((c & 7) ^ ((lane >> 1) & 7))) << 4);
+            const int off = lane * (AX_VKEYS * 2) + (G::vpos(c, lane) << 4);
             *reinterpret_cast<f16x8*>(Vh + off) = hh;
             *reinterpret_cast<f16x8*>(Vl + off) = ll;
         }
@@ -1438,7 +1455,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
     __syncthreads();
 
     const int qi = lane & 15, g = lane >> 4;
-    const int sw = (qi >> 1) & 7;                      // swizzle of this lane's K row / V^T row (rows 16 kt + qi, 16 dt + qi)
+    const int sw = (qi >> 1) & 7;                      // swizzle of this lane's K row (rows 16 kt + qi)
+    const int sw_last = ((L - 1) >> 1) & 7;            // ... and of row L - 1, which stands in for keys >= L
     const int nqt = (L + 15) / 16;
     for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + qi;
@@ -1470,13 +1488,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
         for (int kt = 0; kt < AX_KT; kt += 2) {
             const bool two = kt + 1 < AX_KT;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            const int r0 = (kt * 16 + qi) * 128, r1 = ((kt + 1) * 16 + qi) * 128;
+            // keys >= L (last tile only) read row L - 1: their scores are masked to -inf below
+            const int r0 = min(kt * 16 + qi, L - 1) * 128, r1 = min((kt + 1) * 16 + qi, L - 1) * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int co = ((4 * ks + g) ^ sw) << 4;
-                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(Kh + r0 + co), kl0 = *reinterpret_cast<const f16x8*>(Kl + r0 + co);
+                const int co0 = ((4 * ks + g) ^ (kt * 16 + qi < L ? sw : sw_last)) << 4;
+                const int co1 = ((4 * ks + g) ^ ((kt + 1) * 16 + qi < L ? sw : sw_last)) << 4;
+                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(Kh + r0 + co0), kl0 = *reinterpret_cast<const f16x8*>(Kl + r0 + co0);
                 f16x8 kh1 = kh0, kl1 = kl0;
-                if (two) { kh1 = *reinterpret_cast<const f16x8*>(Kh + r1 + co); kl1 = *reinterpret_cast<const f16x8*>(Kl + r1 + co); }
+                if (two) { kh1 = *reinterpret_cast<const f16x8*>(Kh + r1 + co1); kl1 = *reinterpret_cast<const f16x8*>(Kl + r1 + co1); }
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[ks], acc0, 0, 0, 0);
                 if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[ks], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[ks], acc0, 0, 0, 0);
@@ -1521,7 +1541,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 1) attn_x3_k(const float* __restr
                 ph[j] = xh; pl[j] = (_Float16)(x - (float)xh);
             }
             const int c = 4 * t + g;
-            const int co = ((c & ~7) | ((c & 7) ^ sw)) << 4;
+            const int co = G::vpos(c, qi) << 4;        // rows 16 dt + qi: 16 dt touches neither bits 1..3 nor bits 2..3 of the row
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int ro = (16 * dt + qi) * (AX_VKEYS * 2) + co;
