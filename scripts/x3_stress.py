@@ -29,3 +29,14 @@ for drop in ("off", "faithful"):
             rows = np.argwhere(d.max(axis=2) > 1e-4)
             print(kind, drop, "run", i, "differs: max err", float(d.max()), "bad (row,slot) count", len(rows), rows[:6].tolist(), flush=True)
     print(kind, drop, "runs", n, "bad", bad, "max err vs fp32 (run 0)", float(np.abs(first - ref).max()), flush=True)
+
+# ---- complete samples (graph replay, two lanes): repeated runs must give identical tokens --------------------------------
+Bs = 256
+big = E.eval_batch("huab348" if kind == "ab" else "vhh", Bs, row0=0)
+T = np.minimum(big["T"], 24)
+for name, m in (("fp32", m0), ("x3", m1)):
+    outs = [m.sample(big["tokens"], big["region"], big["chain"], big["order"], T, seed=5, row0=0) for _ in range(4)]
+    same = all(np.array_equal(outs[0], o) for o in outs[1:])
+    print(kind, name, "24-step samples of 256 rows x4 identical:", same, flush=True)
+print(kind, "x3 tokens == fp32 tokens:", bool(np.array_equal(m0.sample(big["tokens"], big["region"], big["chain"], big["order"], T, seed=5, row0=0),
+                                                                 m1.sample(big["tokens"], big["region"], big["chain"], big["order"], T, seed=5, row0=0))))

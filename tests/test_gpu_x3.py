@@ -105,6 +105,25 @@ def test_x3_samples_equal_fp32_samples(hip, kind):
         m32.close(); mx3.close()
 
 
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_x3_is_deterministic(hip, kind):
+    """Repeated forwards of one batch must be bit-identical.  (A first nanobody attention kernel whose two co-resident
+    blocks filled a CU's LDS exactly produced different wrong rows in almost every forward)"""
+    from hudiff_amd import evalsets as E
+    cfg, sd, m32, mx3 = _pair(hip, kind, seed=0)
+    try:
+        B = 64 if kind == "ab" else 128
+        batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
+        kw = dict(dropout="faithful", seed=9, row0=0, step=1)
+        ref = m32(batch["tokens"], batch["region"], batch["chain"], **kw)
+        first = mx3(batch["tokens"], batch["region"], batch["chain"], **kw)
+        assert np.abs(first - ref).max() < LOGIT_TOL
+        for _ in range(7):
+            assert np.array_equal(mx3(batch["tokens"], batch["region"], batch["chain"], **kw), first)
+    finally:
+        m32.close(); mx3.close()
+
+
 def test_x3_off_by_default_and_on_small_shapes(hip):
     """Without HUDIFF_X3 nothing changes; with it, shapes the 128 x 128 x 32 tiles do not cover (the micro goldens) run
     the fp32 kernels and stay bit-exact against the reference traces."""
