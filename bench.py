@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-split-line", action="store_true",
                     help="skip the extra `split_precision` leg (same workload on the HUDIFF_X3=1 kernels, reported beside the f32 metric)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--loop-graph", action="store_true", help="the whole T-step loop of a lane as ONE hipGraph (HD_LOOP_GRAPH) "
+                    "instead of T replays of the step graph")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="2 = the batch runs as two concurrent half-batches on two streams (library default)")
     return ap.parse_args()
@@ -172,7 +174,7 @@ def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, f
     logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
     dmax = float(np.abs(logits - ref_logits).max())
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
-                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph, lanes=args.lanes)
+                       row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
     gpu_ms = 0.0
     for i in range(-args.warmup, args.steps):
         model.sample_restart(2023 + 7919 * i)
@@ -294,7 +296,7 @@ def main():
 
     t_up0 = time.perf_counter()
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
-                       row0=rank * B, dropout=args.dropout, graph=not args.no_graph, lanes=args.lanes)
+                       row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
     upload_s = time.perf_counter() - t_up0
     gpu_ms = 0.0
 

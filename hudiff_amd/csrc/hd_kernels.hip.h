@@ -141,6 +141,7 @@ struct GemmP {
     // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
     // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
     // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
+    int st_nt;                        // epilogue stores carry the non-temporal policy (streamed outputs do not displace operand lines in L2)
     int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tiles,
                                       // 3 = neither (epilogue only), 4 = one LDS fragment read per k step
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
@@ -277,7 +278,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const int rr = it * RPI + e_r;
             const int g0 = wrow0 + 32 * i + it * RPI;                           // uniform
             const int lrow = g0 + e_r;
-            const bool valid = lrow < seg_rows && col_ok;
+            const bool valid = lrow < seg_rows && col_ok && !(p.x3_abl & 32);      // probe bit 5: every store switched off
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
                 if (p.Wx) v *= p.acc_scale;                               // split-precision operands were scaled by powers of two
@@ -313,7 +314,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
                     p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
+                if (p.st_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
             }
             if (p.c_split || p.C2) {
                 // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
@@ -324,8 +326,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 float* base = p.c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
                 const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
+                if (p.st_nt) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
+                }
             }
             if (p.part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
@@ -736,6 +743,10 @@ __device__ __forceinline__ void lds_barrier() {
 // under load -- four times the MFMA time of a 128 x 128 x 32 tile -- so with two stages the loop is bound by that latency
 // (DMA-only ablation: 24 round trips per block); the big launches use three stages of 256 x 128 tiles (144 KB, one block of
 // eight waves per CU).
+// Persistent blocks: the grid is (at most) as many blocks as fit on the chip at once and each walks over output tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  Before a tile's epilogue the first operand tile of the NEXT output tile is put in
+// flight (stage 0; the epilogue transposes through stage 1's memory), so that neither the DMA round trip at the start of a
+// tile nor the drain of the epilogue's stores is exposed.
 template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 1) gemm_x3_k(const GemmP p) {
     constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
@@ -745,61 +756,67 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     constexpr int A_BYTES = 2 * BM * 64, W_BYTES = 2 * BN * 64;         // (hi, lo) images of BM / BN rows x 32 halfs
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int LOOP_FLOATS = NS * STAGE_BYTES / 4;
-    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
+    constexpr int EPI_BASE = STAGE_BYTES / 4;                            // the epilogue's scratch starts at stage 1
+    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_BASE + EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_BASE + EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
     static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0, "tile / wave split");
+    static_assert(NS >= 2, "the cross-tile prefetch needs a stage the epilogue does not touch");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A hi, A lo, W hi, W lo
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bx, by, seg = 0;
-    {
-        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
-        by = slot % p.tiles_n;
-        bx = (slot / p.tiles_n) * 8 + xcd;
-        if (bx >= p.tiles_m) return;
-    }
-    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
-    const int Lc = p.sg.len[seg];
-    const int seg_rows = p.sg.B * Lc;
-    const int rbase = p.sg.base[seg];
-    const int m0 = bx * BM, n0 = by * BN;
+    const int abl_mode = p.x3_abl & 7;                 // probes only (scripts/x3_probe.hip); bit 3 = no epilogue
     const int Kc = p.Kc;
     const int nkt_tap = Kc / BK;
     const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
-    // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
-    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
+    const int total = ((p.tiles_m + 7) / 8) * 8 * p.tiles_n;
 
-    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
-        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
-        for (int r = tid; r < BM; r += NT) {
-            const int lrow = m0 + r;
-            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
-        }
-        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
-    }
-    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
-    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
-    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
+    // ---- per output tile state (set(t)) ------------------------------------------------------------------------------
+    int seg = 0, Lc = 0, seg_rows = 0, rbase = 0, m0 = 0, n0 = 0, by = 0;
     constexpr uint32_t BUF_OOB = 0x80000000u;
     int a_pos[A_PIECES];
     long a_row[A_PIECES];
     bool a_ok[A_PIECES];
     uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t w_rs = a_rs;
+    // tile index -> (M tile, N tile): all N tiles of an M tile on one XCD (see gemm_k); gridDim.x is a multiple of 8
+    auto tile_bx = [&](int t) { const int xcd = t & 7, slot = t >> 3; return (slot / p.tiles_n) * 8 + xcd; };
+    auto next_tile = [&](int t) {                     // next tile of this block that has rows (the M tile count is padded to 8)
+        t += gridDim.x;
+        while (t < total && tile_bx(t) >= p.tiles_m) t += gridDim.x;
+        return t;
+    };
+    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
+    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
+    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
+    auto set = [&](int t) {
+        int bx = tile_bx(t);
+        by = (t >> 3) % p.tiles_n;
+        seg = 0;
+        if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+        Lc = p.sg.len[seg];
+        seg_rows = p.sg.B * Lc;
+        rbase = p.sg.base[seg];
+        m0 = bx * BM; n0 = by * BN;
+        // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
+        const uint16_t* Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
+        w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) {
-        const int piece = NW * i + wave;                                 // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
-        const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
-        const int lrow = m0 + r;
-        a_ok[i] = lrow < seg_rows;
-        a_pos[i] = CONV ? (lrow % Lc) : 0;
-        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
-        a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
-        a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
-    }
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int piece = NW * i + wave;                             // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
+            const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
+            const int lrow = m0 + r;
+            a_ok[i] = lrow < seg_rows;
+            a_pos[i] = CONV ? (lrow % Lc) : 0;
+            a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
+            a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
+            a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
         const int piece = NW * i + wave;                                 // LDS image: hi plane of all BN rows, then lo plane
@@ -807,8 +824,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         const int t128 = rg / 8, rg8 = rg % 8;                           // which 128-column tile, row group within it
         w_vo[i] = (uint32_t)(t128 * nkt * X3_TILE_BYTES + plane * (X3_TILE_BYTES / 2) + rg8 * 1024 + lane * 16);
     }
-    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_vp;
     auto dma = [&](int kt, int st) {
         const int tap = CONV ? kt / nkt_tap : 0;
@@ -833,13 +848,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     // fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
     // chunk ^ ((r >> 2) & 3); the wave part and 32 t do not touch bits 2..3 of r
     const int fsw = (lane >> 2) & 3, fg = lane >> 5;
@@ -851,13 +859,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int o = ks ? foff1 : foff0;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-            if (p.x3_abl == 4) {                       // probe: one fragment read per k step instead of 2 (TM + TN)
-                const f16x8 f = *reinterpret_cast<const f16x8*>(At + o);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) { ah[i] = f; al[i] = f; }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { bh[j] = f; bl[j] = f; }
-            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(At + o + 32 * 64 * i);
@@ -867,7 +868,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(Wt + o + 32 * 64 * j);
                 bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + o + 32 * 64 * j);
-            }
             }
             // the two cross terms first, the leading term last: TM x TN independent accumulators per term
 #pragma unroll
@@ -884,29 +884,70 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    // s_waitcnt vmcnt(n): this wave's DMA instructions except the n most recent have landed.  In the steady state the tiles
-    // issued after tile kt+1 are kt+2 .. kt+NS-1, i.e. (NS - 2) * (A_PIECES + W_PIECES) instructions.
+    // s_waitcnt vmcnt(n): this wave's vector-memory instructions except the n most recent have completed.  In the steady
+    // state the tiles issued after tile kt+1 are kt+2 .. kt+NS-1, i.e. (NS - 2) * (A_PIECES + W_PIECES) instructions.
     constexpr int PER_TILE = A_PIECES + W_PIECES, KEEP = (NS - 2) * PER_TILE;
     static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
     constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
+
+    int t = blockIdx.x;
+    if (tile_bx(t) >= p.tiles_m) t = next_tile(t);
+    bool in_flight = false;                            // k tile 0 of output tile t is already on its way to stage 0
+    if (t < total) set(t);
+    while (t < total) {
+        if (p.ln_fold) {                               // folded LayerNorm: the epilogue needs rstd of every row of the tile
+            float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+            for (int r = tid; r < BM; r += NT) {
+                const int lrow = m0 + r;
+                rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+            }
+            // visible to every wave after the barriers of the K loop (each tile runs at least one k tile)
+        }
 #pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nkt) dma(t, t);
-    if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
-    lds_barrier();
-    int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + NS - 1 < nkt;
-        // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
-        if (more && p.x3_abl != 2 && p.x3_abl != 3) dma(kt + NS - 1, st_in);
-        if (p.x3_abl != 1 && p.x3_abl != 3) mma(st);
-        // tile kt+1 must have landed before the next iteration reads it ...
-        if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-        lds_barrier();                                 // ... everybody's part of it; everybody is done reading tile kt
-        st_in = st;
-        st = st + 1 == NS ? 0 : st + 1;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (!in_flight) dma(0, 0);
+#pragma unroll
+        for (int s = 1; s < NS - 1; ++s)
+            if (s < nkt) dma(s, s);
+        if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // k tile 0 has landed
+        lds_barrier();
+        int st = 0, st_in = NS - 1;                    // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + NS - 1 < nkt;
+            // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
+            if (more && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
+            if (abl_mode != 1 && abl_mode != 3) mma(st);
+            // tile kt+1 must have landed before the next iteration reads it ...
+            if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            lds_barrier();                             // ... everybody's part of it; everybody is done reading tile kt
+            st_in = st;
+            st = st + 1 == NS ? 0 : st + 1;
+        }
+        // the epilogue's view of this tile, then the next tile's first operands go out (stage 0; nobody reads a stage now)
+        const int e_seg = seg, e_rows = seg_rows, e_rbase = rbase, e_Lc = Lc, e_m0 = m0, e_n0 = n0, e_by = by;
+        t = next_tile(t);
+        in_flight = false;
+        if (t < total && !(p.x3_abl & 16)) { set(t); dma(0, 0); in_flight = true; }
+        else if (t < total) set(t);
+        if (p.x3_abl & 8) {                            // probe: no epilogue (the accumulators stay live through a never-true store)
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+            if (s == 1.2345678f) p.C[tid] = s;
+        } else {
+            gemm_epilogue<BM, BN, WM, WN>(p, acc, smem + EPI_BASE, reinterpret_cast<const float2*>(smem + WORK_FLOATS), e_seg, e_rows, e_rbase,
+                                          e_Lc, e_m0, e_n0, e_by);
+        }
+        if (t < total) lds_barrier();                  // the scratch (stage 1) and the row statistics are free again
     }
-    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
 // ------------------------------------------------------------------------------------------------

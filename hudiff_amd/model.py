@@ -166,7 +166,9 @@ class _Denoiser:
     @staticmethod
     def _flags(dropout, graph=True, prune=True, lanes=2):
         f = {"faithful": L.HD_DROPOUT_FAITHFUL, "off": L.HD_DROPOUT_OFF, "inject": L.HD_DROPOUT_INJECT}[dropout]
-        return f | (0 if graph else L.HD_NO_GRAPH) | (0 if prune else L.HD_NO_PRUNE) | (0 if lanes == 2 else L.HD_ONE_LANE)
+        # graph: True = one hipGraph per step replayed T times, "loop" = the whole T-step loop as one hipGraph, False = eager
+        return (f | (0 if graph else L.HD_NO_GRAPH) | (L.HD_LOOP_GRAPH if graph == "loop" else 0) | (0 if prune else L.HD_NO_PRUNE)
+                | (0 if lanes == 2 else L.HD_ONE_LANE))
 
     def forward(self, H_L_seq, H_L_region_type, H_L_chn_type=None, *, dropout="faithful", seed=0, row0=0,
                 step=0, enc_masks=None, conv_masks=None):

@@ -69,7 +69,7 @@ def test_forward_generated_dropout_matches_oracle_contract(micro):
 
 
 @pytest.mark.parametrize("mode", ["finetune", "plain", "inpaint"])
-@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("graph", [True, False, "loop"])
 def test_full_sampling_trace_bit_exact(micro, mode, graph):
     if (micro["kind"] == "ab") != (mode == "finetune"):
         pytest.skip("mode belongs to the other model")
@@ -110,6 +110,21 @@ def test_two_lanes_equal_one_lane(micro):
                      None if batch["chain"] is None else np.concatenate([batch["chain"][36:40], batch["chain"][B + 36:B + 40]]),
                      batch["order"][36:40], T[36:40], q_noise=q[:, 36:40])
     assert np.array_equal(two[36:40], want)          # rows of the second lane against the oracle
+
+
+def test_loop_graph_equals_step_graph_replays(micro):
+    """HD_LOOP_GRAPH: the T-step loop as ONE hipGraph (a chain of child-graph nodes) = T replays of the step graph; the loop
+    graph is cached per step count and rebuilt when the count changes; ragged T, two lanes, generated dropout."""
+    from hudiff_amd import synthetic as S
+    B = 70
+    batch = S.synthetic_batch(micro["kind"], B, seed=35)
+    for tcap in (7, 4, 7):
+        T = np.minimum(batch["T"], tcap); T[3] = 0; T[50] = 2
+        order = batch["order"][:, :tcap]
+        kw = dict(seed=424242, row0=300, dropout="faithful")
+        step = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], order, T, graph=True, **kw)
+        loop = micro["m1"].sample(batch["tokens"], batch["region"], batch["chain"], order, T, graph="loop", **kw)
+        assert np.array_equal(step, loop)
 
 
 def test_cached_graphs_survive_workspace_regrowth(micro):
