@@ -192,6 +192,10 @@ def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, f
     return tokens, {"value": round(B * args.steps / elapsed, 4), "unit": "sequences/s", "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                     "dtype": "fp32 operands split as fp16 hi + fp16 lo, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
                     "algorithmic_tflops": round(tf, 3), "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
+                    # three fp16 MFMAs per fp32 product: matrix-pipe rate against the dense fp16 peak of the guide (2.4 GHz;
+                    # the sample sustains ~2.0 GHz at the 1.4 kW package limit)
+                    "roofline": {"bound": "mfma", "achieved": round(3 * tf, 2), "peak": 2500.0,
+                                 "unit": "TFLOP/s (fp16 MFMA, 3 per product)", "frac": round(3 * tf / 2500.0, 4)},
                     "max_abs_dlogit_vs_f32_path": dmax, "dlogit_rows": ref_rows,
                     "note": "HUDIFF_X3=1 prototype (DESIGN.md section 9): Q|K|V, out-projection, FF and tap GEMMs; the remaining "
                             "kernels are the f32 ones.  Not the metric."}

@@ -52,6 +52,13 @@ python $R/scripts/rocpd_summary.py $(find $OUT/x3trace -name "*.db" | head -1) -
 python $R/scripts/x3_eval.py ab 2>/dev/null | tail -1 > $OUT/x3_eval_ab.json
 python $R/scripts/x3_eval.py nb 2>/dev/null | tail -1 > $OUT/x3_eval_nb.json
 rm -rf $OUT/x3stats $OUT/x3trace
+# ---- clock / power while sampling (rocm-smi polled at ~10 Hz) and the isolated Q|K|V split-precision launch (scripts/x3_probe.hip)
+B2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --traffic off --no-split-line"
+{ HUDIFF_X3=0 bash $R/scripts/smi_watch.sh f32_ab $B2 2>&1 | grep SMI
+  HUDIFF_X3=1 bash $R/scripts/smi_watch.sh x3_ab $B2 2>&1 | grep SMI
+  HUDIFF_X3=0 bash $R/scripts/smi_watch.sh f32_nb $B2 --kind nb --steps 8 2>&1 | grep SMI
+  HUDIFF_X3=1 bash $R/scripts/smi_watch.sh x3_nb $B2 --kind nb --steps 8 2>&1 | grep SMI; } > $OUT/clock_power.txt
+[ -x $R/scripts/x3_probe.bin ] && timeout 120 $R/scripts/x3_probe.bin 2>&1 | grep -E "END|MON" > $OUT/x3_probe_qkv.txt
 echo "$HEAD" > $OUT/GIT_HEAD
 rm -rf $OUT/stats $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_* $OUT/pmc_TCC_*
 ls -la $OUT

@@ -1,5 +1,5 @@
-// Probe (scripts only): gemm_x3_k on the Q|K|V shape, ablations, each held for ~1.5 s so that clocks / power can be sampled
-// from outside (scripts/x3_probe.sh polls rocm-smi).  hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/x3_probe.hip -o scripts/x3_probe.bin
+// Probe (scripts only): gemm_x3_k alone on the Q|K|V shape with its ablation knobs (GemmP::x3_abl), 0.6 s per variant, plus a
+// monitor wave that measures the shader clock (scripts/x3_probe.sh SMI=1 also polls rocm-smi).  hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/x3_probe.hip -o scripts/x3_probe.bin
 #include "../hudiff_amd/csrc/hd_kernels.hip.h"
 #include <chrono>
 #include <cstdio>
@@ -101,15 +101,17 @@ int main() {
     printf("start\n"); fflush(stdout); mon_start(); mon_stop("idle"); fflush(stdout);
     const double gf = 2.0 * M * K * N * 1e-9;
     const double secs = 0.6;
-    for (int pers : {0, 1}) {
-        g_persist = pers;
+    // the table of DESIGN.md section 9: x3_abl 0 = everything, 8 = no epilogue, 8+1 = operand DMA only, 8+2 = MFMAs + fragment
+    // reads only, 8+3 = barriers / set-up only, 3 = epilogue only, 32+3 = epilogue without its stores
+    for (int abl : {0, 8, 9, 10, 11, 3, 32 + 3}) run<128, 128, 2, 2, 2>(p, abl, secs, "128x128x2");
+    for (int abl : {0, 8, 9, 10, 11, 3, 32 + 3}) run<256, 256, 2, 4, 2>(p, abl, secs, "256x256x2");
+    for (int pers : {0, 1})
         for (int nt : {0, 1}) {
-            p.st_nt = nt;
+            g_persist = pers; p.st_nt = nt;
             char tag[64];
-            snprintf(tag, sizeof tag, "128x128x2 persist=%d nt=%d", pers, nt); for (int abl : {0, 16}) run<128, 128, 2, 2, 2>(p, abl, secs, tag);
-            snprintf(tag, sizeof tag, "256x256x2 persist=%d nt=%d", pers, nt); for (int abl : {0, 16}) run<256, 256, 2, 4, 2>(p, abl, secs, tag);
+            snprintf(tag, sizeof tag, "128x128x2 persist=%d nt=%d", pers, nt); run<128, 128, 2, 2, 2>(p, 0, secs, tag);
+            snprintf(tag, sizeof tag, "256x256x2 persist=%d nt=%d", pers, nt); run<256, 256, 2, 4, 2>(p, 0, secs, tag);
         }
-    }
     printf("GF %.1f\n", gf);
     return 0;
 }
