@@ -998,7 +998,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
     if (x3 && ax_on && m->L > 160 && m->L <= AX_KROWS)
-        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<19>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
     else if (x3 && ax_on && m->L <= 160) {
         hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
     } else if (m->L > 160)

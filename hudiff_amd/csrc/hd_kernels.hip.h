@@ -1418,14 +1418,18 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                                                             float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
     typedef AxGeom<KT> G;
     constexpr int AX_KT = KT, AX_KROWS = G::KROWS, AX_VKEYS = G::VKEYS, AX_KPLANE = G::KPLANE, AX_VPLANE = G::VPLANE;
-    // K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the nanobody model that is
-    // 79 872 B -- two blocks per CU with 4 KB to spare.  (With 160 zero-padded rows the block took 81 920 B, two blocks filled
-    // the CU's 163 840 B exactly, and blocks that started beside a running one produced wrong rows now and then.)
+    // KT <= 10 (EXACT): the K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the
+    // nanobody model that is 79 872 B -- two blocks per CU with 4 KB to spare.  (With 160 zero-padded rows the block took 81 920 B,
+    // two blocks filled the CU's 163 840 B exactly, and blocks that started beside a running one produced wrong rows now and then.)
+    // Reads of keys >= L are then redirected to row L - 1 (their scores are masked anyway).  KT = 19 runs one block per CU: its
+    // planes keep 16 KT zero-padded rows and the K loop carries no clamps (they cost 317 vs 272 us per launch).
+    constexpr bool EXACT = KT <= 10;
     extern __shared__ __attribute__((aligned(16))) char axs[];
     const int L = sg.L;
+    const int krows = EXACT ? L : AX_KROWS;
     char* Kh = axs;
-    char* Kl = axs + L * 128;
-    char* Vh = axs + 2 * L * 128;
+    char* Kl = axs + krows * 128;
+    char* Vh = axs + 2 * krows * 128;
     char* Vl = Vh + AX_VPLANE;
     const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1462,12 +1466,13 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int idx = tid + ATT_THREADS * k;
-            if (idx < L * 16) {
+            if (idx < krows * 16) {
                 const int key = idx >> 4, c4 = (idx & 15) * 4;
                 const f32x4 kv = kb[k];
                 f32x4 kr;
                 kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
                 kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
+                if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
                 const f16x4 hh = __builtin_convertvector(kr, f16x4);
                 const f16x4 ll = __builtin_convertvector(kr - __builtin_convertvector(hh, f32x4), f16x4);
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
@@ -1530,11 +1535,12 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
             const bool two = kt + 1 < AX_KT;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             // keys >= L (last tile only) read row L - 1: their scores are masked to -inf below
-            const int r0 = min(kt * 16 + qi, L - 1) * 128, r1 = min((kt + 1) * 16 + qi, L - 1) * 128;
+            const int r0 = (EXACT ? min(kt * 16 + qi, L - 1) : kt * 16 + qi) * 128;
+            const int r1 = (EXACT ? min((kt + 1) * 16 + qi, L - 1) : (kt + 1) * 16 + qi) * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int co0 = ((4 * ks + g) ^ (kt * 16 + qi < L ? sw : sw_last)) << 4;
-                const int co1 = ((4 * ks + g) ^ ((kt + 1) * 16 + qi < L ? sw : sw_last)) << 4;
+                const int co0 = ((4 * ks + g) ^ (!EXACT || kt * 16 + qi < L ? sw : sw_last)) << 4;
+                const int co1 = ((4 * ks + g) ^ (!EXACT || (kt + 1) * 16 + qi < L ? sw : sw_last)) << 4;
                 const f16x8 kh0 = *reinterpret_cast<const f16x8*>(Kh + r0 + co0), kl0 = *reinterpret_cast<const f16x8*>(Kl + r0 + co0);
                 f16x8 kh1 = kh0, kl1 = kl0;
                 if (two) { kh1 = *reinterpret_cast<const f16x8*>(Kh + r1 + co1); kl1 = *reinterpret_cast<const f16x8*>(Kl + r1 + co1); }

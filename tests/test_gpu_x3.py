@@ -144,3 +144,30 @@ def test_x3_off_by_default_and_on_small_shapes(hip):
         assert np.array_equal(out, z["final"])
     finally:
         m.close()
+
+
+def test_x3_persistent_blocks_and_nontemporal_stores_change_nothing(hip, tmp_path):
+    """HUDIFF_X3_PERSIST=1 (gemm_x3_k blocks walk over several output tiles, the next tile's operands in flight during the
+    epilogue) and HUDIFF_ST_NT=1 (non-temporal epilogue stores) are scheduling / cache-policy knobs read once per process:
+    a child process with both set must produce bit-identical logits to this process's split-precision kernels."""
+    import subprocess
+    import sys
+    from hudiff_amd import evalsets as E
+    code = (
+        "import sys, numpy as np, hudiff_amd\n"
+        "from hudiff_amd import synthetic as S, evalsets as E\n"
+        "cfg = dict(S.AB_CONFIG); sd = S.random_state_dict('ab', cfg, seed=0)\n"
+        "m = hudiff_amd.AntiTFNet(**cfg); m.load_state_dict(sd)\n"
+        "b = E.eval_batch('huab348', 64, row0=0)\n"
+        "np.save(sys.argv[1], m(b['tokens'], b['region'], b['chain'], dropout='faithful', seed=9, row0=0, step=1))\n")
+    out = str(tmp_path / "logits.npy")
+    env = dict(os.environ, HUDIFF_X3="1", HUDIFF_X3_PERSIST="1", HUDIFF_ST_NT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=root, timeout=600)
+    cfg, sd, m32, mx3 = _pair(hip, "ab", seed=0)
+    try:
+        b = E.eval_batch("huab348", 64, row0=0)
+        here = mx3(b["tokens"], b["region"], b["chain"], dropout="faithful", seed=9, row0=0, step=1)
+    finally:
+        m32.close(); mx3.close()
+    assert np.array_equal(np.load(out), here)
