@@ -86,6 +86,62 @@ def physical_cores():
         return logical, logical
 
 
+class ClockPowerSampler:
+    """Shader clock and package power of the GPU this rank runs on, read from the amdgpu hwmon files (freq1_input in Hz,
+    power1_input in uW) every 100 ms by a thread while the timed region runs.  Both paths sit on the package power limit
+    (DESIGN.md section 9), so the sustained clock -- not the 2.4 GHz of the peak figure -- is what the matrix pipe ran at."""
+
+    def __init__(self, device):
+        import threading
+        self.dir, self.f, self.p, self._stop, self._t = None, [], [], threading.Event(), None
+        try:
+            import ctypes, glob
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+                d = glob.glob(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/hwmon/hwmon*")
+                if d and os.path.exists(os.path.join(d[0], "freq1_input")) and os.path.exists(os.path.join(d[0], "power1_input")):
+                    self.dir = d[0]
+        except (OSError, AttributeError):
+            pass
+        if self.dir:
+            self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as fh:
+            return float(fh.read().strip())
+
+    def _run(self):
+        while not self._stop.wait(0.1):
+            try:
+                self.f.append(self._read("freq1_input") * 1e-6)
+                self.p.append(self._read("power1_input") * 1e-6)
+            except (OSError, ValueError):
+                return
+
+    def start(self):
+        if self._t:
+            self._t.start()
+        return self
+
+    def stop(self):
+        if not self._t:
+            return None
+        self._stop.set()
+        self._t.join()
+        busy = [(f, p) for f, p in zip(self.f, self.p) if p > 500.0] or list(zip(self.f, self.p))
+        if not busy:
+            return None
+        med = lambda v: float(sorted(v)[len(v) // 2])
+        out = {"sclk_mhz_median": round(med([f for f, _ in busy]), 1), "power_w_median": round(med([p for _, p in busy]), 1),
+               "samples": len(busy)}
+        try:
+            out["power_cap_w"] = round(self._read("power1_cap") * 1e-6, 1)
+        except (OSError, ValueError):
+            pass
+        return out
+
+
 def make_batch(kind, B, mode, row0, data):
     from hudiff_amd import evalsets as E
     from hudiff_amd import synthetic as S
@@ -176,16 +232,19 @@ def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, f
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
                        row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
     gpu_ms = 0.0
+    watch = None
     for i in range(-args.warmup, args.steps):
         model.sample_restart(2023 + 7919 * i)
         if i == 0:
             model.sync()
+            watch = ClockPowerSampler(local_rank).start()
             t0 = time.perf_counter()
         model.sample_run(0, Tmax)
         if i >= 0:
             model.sync()
             gpu_ms += model.last_run_ms()[0]
     elapsed = time.perf_counter() - t0
+    clock_power = watch.stop() if watch else None
     tokens = model.sample_end()
     model.close()
     tf = float(T.sum()) * flops_row * args.steps / (gpu_ms * 1e-3) / 1e12
@@ -196,7 +255,7 @@ def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, f
                     # the sample sustains ~2.0 GHz at the 1.4 kW package limit)
                     "roofline": {"bound": "mfma", "achieved": round(3 * tf, 2), "peak": 2500.0,
                                  "unit": "TFLOP/s (fp16 MFMA, 3 per product)", "frac": round(3 * tf / 2500.0, 4)},
-                    "max_abs_dlogit_vs_f32_path": dmax, "dlogit_rows": ref_rows,
+                    "clock_power": clock_power, "max_abs_dlogit_vs_f32_path": dmax, "dlogit_rows": ref_rows,
                     "note": "HUDIFF_X3=1 prototype (DESIGN.md section 9): Q|K|V, out-projection, FF and tap GEMMs; the remaining "
                             "kernels are the f32 ones.  Not the metric."}
 
@@ -315,11 +374,13 @@ def main():
     for i in range(args.warmup):
         one_sample(-1 - i, False)
     barrier()
+    watch = ClockPowerSampler(local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_sample(i, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_power = watch.stop() if watch else None
     tokens = model.sample_end()
     split = None
     if rank == 0 and world == 1 and args.max_t == 0 and not args.no_split_line and os.environ.get("HUDIFF_X3", "0") in ("", "0"):
@@ -382,6 +443,12 @@ def main():
                          "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)},
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
         }
+        if clock_power:
+            # the 157.3 TFLOP/s peak is the 2.4 GHz figure; the package power limit decides the clock the kernels really ran at
+            pk = PEAK_F32_MATRIX_TFLOPS * clock_power["sclk_mhz_median"] / 2400.0
+            clock_power.update({"peak_at_sustained_clock": round(pk, 2), "frac_at_sustained_clock": round(achieved / pk, 4),
+                                "source": "amdgpu hwmon freq1_input / power1_input of this GPU, 10 Hz over the timed region"})
+            out["roofline"]["clock_power"] = clock_power
         # HBM-side traffic per launch: live PMC passes of this very command (subprocess, after the timed region), else the
         # committed passes of the round (profiles/r02/pmc_traffic.json, stamped with the commit they were taken at)
         if args.traffic in ("auto", "live") and n_gpus == 1 and args.max_t == 0:
