@@ -798,9 +798,10 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     const bool big = rows >= 8192;
     const int pw = big ? 64 : 32;
     p.part_rows = rows;
-    // non-temporal epilogue stores: +0.9 % on the split-precision sample (3 x 3 interleaved runs), nothing on the fp32 one
-    static const int st_nt = [] { const char* e = getenv("HUDIFF_ST_NT"); return e ? atoi(e) : -1; }();
-    p.st_nt = big ? (st_nt >= 0 ? st_nt : (p.Wx != nullptr)) : 0;
+    // non-temporal epilogue stores: +0.9 % on the split-precision sample (3 x 3 interleaved runs; gemm_x3_k always uses them),
+    // nothing on the fp32 one (HUDIFF_ST_NT=1 turns them on there)
+    static const int st_nt = [] { const char* e = getenv("HUDIFF_ST_NT"); return e ? atoi(e) : 0; }();
+    p.st_nt = big ? st_nt : 0;
     if (stats_out != STATS_NONE || apply) p.part = ws.PART[ws.part_next];
     static const int small_tiles = [] { const char* e = getenv("HUDIFF_GEMM_SMALL"); return e ? atoi(e) : 1536; }();
     const long tiles128 = ((rows + 127) / 128) * ((p.N + 127) / 128);
@@ -838,14 +839,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         q.tiles0 = (rows0 + bm - 1) / bm;
         q.tiles_m = q.tiles0 + (rows1 + bm - 1) / bm;
         q.tiles_n = q.N / bn;
-        // persistent blocks: as many as are resident at once (gemm_x3_k walks over the output tiles), a multiple of 8 (XCDs)
-        static const int cus = [] { int d = 0; hipGetDevice(&d); hipDeviceProp_t pr; hipGetDeviceProperties(&pr, d);
-                                    return pr.multiProcessorCount > 0 ? pr.multiProcessorCount / 8 * 8 : 256; }();
-        static const int persist = [] { const char* e = getenv("HUDIFF_X3_PERSIST"); return e ? atoi(e) : 0; }();
-        const unsigned tiles = ((q.tiles_m + 7) / 8) * 8 * q.tiles_n;
-        const unsigned resident = (unsigned)cus * (shape == 128 ? 2 : 1);
-        dim3 grid(persist && tiles > resident ? resident : tiles);
-        if (persist == 2) q.x3_abl |= 16;              // persistent walk without the cross-tile prefetch (A/B)
+        dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n);
         if (shape == 512) {
             if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, true, 2>), grid, dim3(512), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<256, 256, 2, 4, false, 2>), grid, dim3(512), 0, st, q);

@@ -141,7 +141,8 @@ struct GemmP {
     // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
     // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
     // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
-    int st_nt;                        // epilogue stores carry the non-temporal policy (streamed outputs do not displace operand lines in L2)
+    int st_nt;                        // fp32 kernels: epilogue stores carry the non-temporal policy (gemm_x3_k always stores non-temporally:
+                                      // streamed outputs then do not displace operand lines in L2)
     int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tiles,
                                       // 3 = neither (epilogue only), 4 = one LDS fragment read per k step
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
@@ -208,7 +209,19 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // with 16-B stores and (optionally) leaves the LayerNorm slice partials of the rows it wrote.
 // smem must hold NW * 32 * (BN/WN + 4) + NW * (BM/WM) * 2 floats (NW = WM * WN waves) and be free (all waves past their
 // last LDS read).
-template <int BM, int BN, int WM, int WN>
+// F: the epilogue features that MAY be present (each is still tested at run time); a caller that knows a launch uses only a few
+// of them instantiates the epilogue with those bits, and the code of the others -- their descriptors, scalar loads and
+// branches, 35 % of the vector-ALU instructions of a plain launch -- is not compiled in.  gemm_x3_k picks the smallest of a
+// handful of masks that covers the launch (three fp16 MFMAs per product make the K loop 5x shorter than the fp32 one, so
+// the epilogue is a third of the matrix time of the short-K projections there).
+enum : int { EPI_FOLD = 1, EPI_ACT = 2, EPI_RESID = 4, EPI_DROP = 8, EPI_EXTRA = 16, EPI_PART = 32, EPI_CSPLIT = 64, EPI_C2 = 128,
+             EPI_ALL = 255,
+             EPI_X3 = 256 };      // set by gemm_x3_k on every mask: acc_scale always applies, stores are non-temporal
+__device__ __forceinline__ int epi_needs(const GemmP& p) {
+    return (p.ln_fold ? EPI_FOLD : 0) | (p.epi_act ? EPI_ACT : 0) | (p.resid ? EPI_RESID : 0) | (p.drop_mode != DROP_NONE ? EPI_DROP : 0) |
+           (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0);
+}
+template <int BM, int BN, int WM, int WN, int F = EPI_ALL>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
                                               int by) {
@@ -224,7 +237,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int N = p.N;
     const float* __restrict__ bias = p.bias ? p.bias + seg * p.n_stride : nullptr;
     uint32_t k0 = 0, k1 = 0, row0 = 0;
-    if (p.drop_mode == DROP_GEN) {
+    const int drop_mode = (F & EPI_DROP) ? p.drop_mode : DROP_NONE;
+    const int epi_act = (F & EPI_ACT) ? p.epi_act : 0;
+    const bool has_resid = (F & EPI_RESID) && p.resid, has_extra = (F & EPI_EXTRA) && p.extra, has_part = (F & EPI_PART) && p.part;
+    const bool ln_fold = (F & EPI_FOLD) && p.ln_fold, c_split = (F & EPI_CSPLIT) && p.c_split, has_c2 = (F & EPI_C2) && p.C2;
+    float acc_scale = p.acc_scale;
+    asm volatile("" : "+v"(acc_scale));      // kept in a VGPR: the compiler otherwise re-loads it from the kernel arguments per row group
+    if (drop_mode == DROP_GEN) {
         uint32_t o[4];
         philox4x32_10(0u, 0u, p.rs->step, p.drop_site, p.rs->seed_lo, p.rs->seed_hi, o);
         k0 = o[0]; k1 = o[1]; row0 = p.rs->row0;
@@ -256,7 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
         // while the accumulators are transposed through LDS instead of serialising load -> store per row
         f32x4 rres[32 / RPI];
-        if (p.resid) {
+        if (has_resid) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int g0 = wrow0 + 32 * i + it * RPI;                       // uniform
@@ -281,15 +300,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const bool valid = lrow < seg_rows && col_ok && !(p.x3_abl & 32);      // probe bit 5: every store switched off
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
-                if (p.Wx) v *= p.acc_scale;                               // split-precision operands were scaled by powers of two
-                if (p.ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
+                if ((F & EPI_X3) || p.Wx) v *= acc_scale;                               // split-precision operands were scaled by powers of two
+                if (ln_fold) v *= rowst[wm * WTM + 32 * i + rr].y;      // folded LayerNorm: rstd * (x W''); beta W + b is in `bias`
+                v += bv;
+                if (epi_act == ACT_RELU) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = act_f(v[c] + bv[c], p.epi_act);
-                if (p.resid) v += rres[it];
-                if (p.drop_mode != DROP_NONE) {
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.0f);
+                } else if (epi_act == ACT_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+                }
+                if (has_resid) v += rres[it];
+                if (drop_mode != DROP_NONE) {
                     const int b = lrow / Lc;
                     const int slot = p.sg.off[seg] + (lrow - b * Lc);
-                    if (p.drop_mode == DROP_GEN) {
+                    if (drop_mode == DROP_GEN) {
                         const uint32_t rk = mix32(k0 ^ mix32(row0 + (uint32_t)b + k1));
                         // (slot * N + col + c) * GOLD = h0 + c * GOLD (mod 2^32): one quarter-rate multiply per float4
                         const uint32_t h0 = rk + (uint32_t)(slot * N + col) * 0x9E3779B9U;
@@ -305,28 +330,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     }
                 }
             }
-            if (p.extra) {
+            if (has_extra) {
                 const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(p.extra) + (long)(rbase + g0) * p.lde, 0, BUF_MAX, 0x00020000);
                 v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, (int)(valid ? x_vo : BUF_OFF), 0, 0));
             }
-            if (!p.c_split) {
+            if (!c_split) {
                 const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
                     p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                if (p.st_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 2);
+                if ((F & EPI_X3) || p.st_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 2);
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
             }
-            if (p.c_split || p.C2) {
+            if (c_split || has_c2) {
                 // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
                 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 const h16x4 hh = __builtin_convertvector(v, h16x4);
                 const h16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), h16x4);
-                float* base = p.c_split ? p.C : p.C2;
+                float* base = c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
                 const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
-                if (p.st_nt) {
+                if ((F & EPI_X3) || p.st_nt) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
                 } else {
@@ -334,7 +359,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
                 }
             }
-            if (p.part) {
+            if (has_part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
                 // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
                 // deviations) of its slice with DPP row reductions and the consumer merges the slices exactly
@@ -353,7 +378,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         }
         __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
     }
-    if (p.part) {
+    if (has_part) {
         // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -690,6 +715,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     }
     if (NBUF == 2) __syncthreads();
 
+    // (feature-masked epilogue instantiations as in gemm_x3_k were tried here: four copies of the epilogue behind a branch push this
+    // 128-VGPR kernel into scratch -- 600 spilled registers, half the speed -- and the epilogue is < 10 % of its time anyway)
     gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
@@ -743,10 +770,6 @@ __device__ __forceinline__ void lds_barrier() {
 // under load -- four times the MFMA time of a 128 x 128 x 32 tile -- so with two stages the loop is bound by that latency
 // (DMA-only ablation: 24 round trips per block); the big launches use three stages of 256 x 128 tiles (144 KB, one block of
 // eight waves per CU).
-// Persistent blocks: the grid is (at most) as many blocks as fit on the chip at once and each walks over output tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ...  Before a tile's epilogue the first operand tile of the NEXT output tile is put in
-// flight (stage 0; the epilogue transposes through stage 1's memory), so that neither the DMA round trip at the start of a
-// tile nor the drain of the epilogue's stores is exposed.
 template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 1) gemm_x3_k(const GemmP p) {
     constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
@@ -756,67 +779,62 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     constexpr int A_BYTES = 2 * BM * 64, W_BYTES = 2 * BN * 64;         // (hi, lo) images of BM / BN rows x 32 halfs
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int LOOP_FLOATS = NS * STAGE_BYTES / 4;
-    constexpr int EPI_BASE = STAGE_BYTES / 4;                            // the epilogue's scratch starts at stage 1
-    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_BASE + EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_BASE + EPI_FLOATS + PART_FLOATS;
+    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
     static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0, "tile / wave split");
-    static_assert(NS >= 2, "the cross-tile prefetch needs a stage the epilogue does not touch");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A hi, A lo, W hi, W lo
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int abl_mode = p.x3_abl & 7;                 // probes only (scripts/x3_probe.hip); bit 3 = no epilogue
+    int bx, by, seg = 0;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
+        by = slot % p.tiles_n;
+        bx = (slot / p.tiles_n) * 8 + xcd;
+        if (bx >= p.tiles_m) return;
+    }
+    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+    const int abl_mode = p.x3_abl & 7;                 // probes only (scripts/x3_probe.hip); bit 3 = no epilogue, bit 5 = no stores
+    const int Lc = p.sg.len[seg];
+    const int seg_rows = p.sg.B * Lc;
+    const int rbase = p.sg.base[seg];
+    const int m0 = bx * BM, n0 = by * BN;
     const int Kc = p.Kc;
     const int nkt_tap = Kc / BK;
     const int nkt = nkt_tap * p.taps;
     const int half = (p.taps - 1) / 2;
-    const int total = ((p.tiles_m + 7) / 8) * 8 * p.tiles_n;
+    // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
+    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
 
-    // ---- per output tile state (set(t)) ------------------------------------------------------------------------------
-    int seg = 0, Lc = 0, seg_rows = 0, rbase = 0, m0 = 0, n0 = 0, by = 0;
+    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
+        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += NT) {
+            const int lrow = m0 + r;
+            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+        }
+        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
+    }
+    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
+    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
+    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
     constexpr uint32_t BUF_OOB = 0x80000000u;
     int a_pos[A_PIECES];
     long a_row[A_PIECES];
     bool a_ok[A_PIECES];
     uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
-    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t w_rs = a_rs;
-    // tile index -> (M tile, N tile): all N tiles of an M tile on one XCD (see gemm_k); gridDim.x is a multiple of 8
-    auto tile_bx = [&](int t) { const int xcd = t & 7, slot = t >> 3; return (slot / p.tiles_n) * 8 + xcd; };
-    auto next_tile = [&](int t) {                     // next tile of this block that has rows (the M tile count is padded to 8)
-        t += gridDim.x;
-        while (t < total && tile_bx(t) >= p.tiles_m) t += gridDim.x;
-        return t;
-    };
-    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
-    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
-    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
-    auto set = [&](int t) {
-        int bx = tile_bx(t);
-        by = (t >> 3) % p.tiles_n;
-        seg = 0;
-        if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
-        Lc = p.sg.len[seg];
-        seg_rows = p.sg.B * Lc;
-        rbase = p.sg.base[seg];
-        m0 = bx * BM; n0 = by * BN;
-        // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
-        const uint16_t* Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
-        w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) {
-            const int piece = NW * i + wave;                             // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
-            const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
-            const int lrow = m0 + r;
-            a_ok[i] = lrow < seg_rows;
-            a_pos[i] = CONV ? (lrow % Lc) : 0;
-            a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
-            a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
-            a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
-        }
-    };
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int piece = NW * i + wave;                                 // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
+        const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
+        const int lrow = m0 + r;
+        a_ok[i] = lrow < seg_rows;
+        a_pos[i] = CONV ? (lrow % Lc) : 0;
+        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
+        a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
+        a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
+    }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
         const int piece = NW * i + wave;                                 // LDS image: hi plane of all BN rows, then lo plane
@@ -824,6 +842,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         const int t128 = rg / 8, rg8 = rg % 8;                           // which 128-column tile, row group within it
         w_vo[i] = (uint32_t)(t128 * nkt * X3_TILE_BYTES + plane * (X3_TILE_BYTES / 2) + rg8 * 1024 + lane * 16);
     }
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_vp;
     auto dma = [&](int kt, int st) {
         const int tap = CONV ? kt / nkt_tap : 0;
@@ -848,6 +868,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     };
 
     f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
     // fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
     // chunk ^ ((r >> 2) & 3); the wave part and 32 t do not touch bits 2..3 of r
     const int fsw = (lane >> 2) & 3, fg = lane >> 5;
@@ -859,6 +886,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int o = ks ? foff1 : foff0;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            if (abl_mode == 4) {                       // probe: one fragment read per k step instead of 2 (TM + TN)
+                const f16x8 f = *reinterpret_cast<const f16x8*>(At + o);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { ah[i] = f; al[i] = f; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { bh[j] = f; bl[j] = f; }
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(At + o + 32 * 64 * i);
@@ -868,6 +902,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(Wt + o + 32 * 64 * j);
                 bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + o + 32 * 64 * j);
+            }
             }
             // the two cross terms first, the leading term last: TM x TN independent accumulators per term
 #pragma unroll
@@ -884,70 +919,49 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    // s_waitcnt vmcnt(n): this wave's vector-memory instructions except the n most recent have completed.  In the steady
-    // state the tiles issued after tile kt+1 are kt+2 .. kt+NS-1, i.e. (NS - 2) * (A_PIECES + W_PIECES) instructions.
+    // s_waitcnt vmcnt(n): this wave's DMA instructions except the n most recent have landed.  In the steady state the tiles
+    // issued after tile kt+1 are kt+2 .. kt+NS-1, i.e. (NS - 2) * (A_PIECES + W_PIECES) instructions.
     constexpr int PER_TILE = A_PIECES + W_PIECES, KEEP = (NS - 2) * PER_TILE;
     static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
     constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
-
-    int t = blockIdx.x;
-    if (tile_bx(t) >= p.tiles_m) t = next_tile(t);
-    bool in_flight = false;                            // k tile 0 of output tile t is already on its way to stage 0
-    if (t < total) set(t);
-    while (t < total) {
-        if (p.ln_fold) {                               // folded LayerNorm: the epilogue needs rstd of every row of the tile
-            float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
-            for (int r = tid; r < BM; r += NT) {
-                const int lrow = m0 + r;
-                rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
-            }
-            // visible to every wave after the barriers of the K loop (each tile runs at least one k tile)
-        }
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nkt) dma(t, t);
+    if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
+    lds_barrier();
+    int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + NS - 1 < nkt;
+        // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
+        if (more && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
+        if (abl_mode != 1 && abl_mode != 3) mma(st);
+        // tile kt+1 must have landed before the next iteration reads it ...
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        lds_barrier();                                 // ... everybody's part of it; everybody is done reading tile kt
+        st_in = st;
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+    if (p.x3_abl & 8) {                                // probe: no epilogue (the accumulators stay live through a never-true store)
+        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        if (!in_flight) dma(0, 0);
-#pragma unroll
-        for (int s = 1; s < NS - 1; ++s)
-            if (s < nkt) dma(s, s);
-        if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // k tile 0 has landed
-        lds_barrier();
-        int st = 0, st_in = NS - 1;                    // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
-        for (int kt = 0; kt < nkt; ++kt) {
-            const bool more = kt + NS - 1 < nkt;
-            // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
-            if (more && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
-            if (abl_mode != 1 && abl_mode != 3) mma(st);
-            // tile kt+1 must have landed before the next iteration reads it ...
-            if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-            lds_barrier();                             // ... everybody's part of it; everybody is done reading tile kt
-            st_in = st;
-            st = st + 1 == NS ? 0 : st + 1;
-        }
-        // the epilogue's view of this tile, then the next tile's first operands go out (stage 0; nobody reads a stage now)
-        const int e_seg = seg, e_rows = seg_rows, e_rbase = rbase, e_Lc = Lc, e_m0 = m0, e_n0 = n0, e_by = by;
-        t = next_tile(t);
-        in_flight = false;
-        if (t < total && !(p.x3_abl & 16)) { set(t); dma(0, 0); in_flight = true; }
-        else if (t < total) set(t);
-        if (p.x3_abl & 8) {                            // probe: no epilogue (the accumulators stay live through a never-true store)
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-            if (s == 1.2345678f) p.C[tid] = s;
-        } else {
-            gemm_epilogue<BM, BN, WM, WN>(p, acc, smem + EPI_BASE, reinterpret_cast<const float2*>(smem + WORK_FLOATS), e_seg, e_rows, e_rbase,
-                                          e_Lc, e_m0, e_n0, e_by);
-        }
-        if (t < total) lds_barrier();                  // the scratch (stage 1) and the row statistics are free again
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1.2345678f) p.C[tid] = s;
+        return;
     }
+    // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
+    const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
+    const int need = p.x3_abl & 64 ? EPI_ALL : epi_needs(p);
+#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
+    if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
+    else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
+    else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
+    else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
+    else HD_EPI(EPI_ALL);
+#undef HD_EPI
 }
 
 // ------------------------------------------------------------------------------------------------

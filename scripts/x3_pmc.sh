@@ -19,7 +19,7 @@ import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "gemm_x3_k" not in r["Kernel_Name"] and "attn_k" not in r["Kernel_Name"]:
+        if not any(s in r["Kernel_Name"] for s in ("gemm_x3_k", "attn_k", "attn_x3_k", "ln_apply_k")):
             continue
         k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0] + " g=" + r["Grid_Size"]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1

@@ -3,6 +3,7 @@
 #include "../hudiff_amd/csrc/hd_kernels.hip.h"
 #include <chrono>
 #include <cstdio>
+#include <string>
 #include <thread>
 #include <vector>
 using namespace hd;
@@ -55,14 +56,12 @@ static void fill_test(float* C, size_t bytes) {
     printf("END   hipMemset: %.1f us = %.2f TB/s\n", 1e3 * ms / 20, bytes / (ms / 20 * 1e-3) * 1e-12);
 }
 
-static int g_persist = 1;
 template <int BM, int BN, int WM, int WN, int NS>
 static float run(GemmP q, int abl, double seconds, const char* tag) {
     q.x3_abl = abl;
     const int rows = q.sg.B * q.sg.len[0];
     q.tiles0 = (rows + BM - 1) / BM; q.tiles_m = q.tiles0; q.tiles_n = q.N / BN;
-    unsigned tiles = ((q.tiles_m + 7) / 8) * 8 * q.tiles_n, resident = 256 * (WM * WN == 4 ? 2 : 1);
-    dim3 grid(g_persist && tiles > resident ? resident : tiles), blk(64 * WM * WN);
+    dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(64 * WM * WN);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_x3_k<BM, BN, WM, WN, false, NS>), grid, blk, 0, 0, q);
@@ -83,7 +82,7 @@ static float run(GemmP q, int abl, double seconds, const char* tag) {
     return ms_total / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int M = 74496, K = 768, N = 1536;
     float *A, *C; uint16_t* Wx;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&C, (size_t)M * N * 4);
@@ -100,18 +99,42 @@ int main() {
     hipMalloc(&g_stop, 4); hipMalloc(&g_out, 64); printf("alloc\n"); fflush(stdout); hipStreamCreateWithFlags(&g_ms, hipStreamNonBlocking);
     printf("start\n"); fflush(stdout); mon_start(); mon_stop("idle"); fflush(stdout);
     const double gf = 2.0 * M * K * N * 1e-9;
+    if (argc > 1 && std::string(argv[1]) == "pmc") {
+        // one launch per epilogue configuration, for `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA ...` (scripts/x3_epi_pmc.sh):
+        // what each epilogue feature costs in vector-ALU instructions.  N = 768 (the out-projection / FF2 / PFF3 shape, K = 512).
+        const int N2 = 768, K2 = 512;
+        float *bias, *C2; float2 *part, *stats;
+        hipMalloc(&bias, N2 * 4); hipMemset(bias, 0, N2 * 4);
+        hipMalloc(&C2, (size_t)M * N2 * 4);
+        hipMalloc(&part, (size_t)16 * M * 8); hipMalloc(&stats, (size_t)M * 8); hipMemset(stats, 0, (size_t)M * 8);
+        GemmP q = p; q.N = N2; q.Kc = K2; q.lda = K2; q.ldc = N2; q.a_bytes = (uint32_t)((size_t)M * K2 * 4);
+        q.tiles0 = M / 128; q.tiles_m = q.tiles0; q.tiles_n = N2 / 128;
+        auto go = [&](const char* name, GemmP g) {
+            printf("PMC %s\n", name);
+            hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2>), dim3(((g.tiles_m + 7) / 8) * 8 * g.tiles_n), dim3(256), 0, 0, g);
+            hipDeviceSynchronize();
+        };
+        GemmP g = q; go("0 plain (scale, fp32 store)", g);
+        g = q; g.x3_abl = 8; go("1 no epilogue at all", g);
+        g = q; g.bias = bias; go("2 + bias", g);
+        g = q; g.bias = bias; g.resid = C; g.ldr = N2; go("3 + bias + residual", g);
+        g = q; g.bias = bias; g.resid = C; g.ldr = N2; g.part = part; g.part_rows = M; go("4 + bias + residual + LayerNorm partials", g);
+        g = q; g.bias = bias; g.resid = C; g.ldr = N2; g.part = part; g.part_rows = M; g.C2 = C2; go("5 + bias + residual + partials + split copy (out-projection / FF2)", g);
+        g = q; g.bias = bias; g.c_split = 1; go("6 bias + split output only (FF1 without ReLU)", g);
+        g = q; g.bias = bias; g.c_split = 1; g.epi_act = ACT_RELU; go("7 bias + ReLU + split output (FF1)", g);
+        g = q; g.bias = bias; g.c_split = 1; g.ln_fold = 1; g.stats = stats; go("8 folded LayerNorm + bias + split output (Q|K|V)", g);
+        g = q; g.bias = bias; g.part = part; g.part_rows = M; go("9 bias + partials (PFF1 / tap GEMM)", g);
+        return 0;
+    }
     const double secs = 0.6;
     // the table of DESIGN.md section 9: x3_abl 0 = everything, 8 = no epilogue, 8+1 = operand DMA only, 8+2 = MFMAs + fragment
     // reads only, 8+3 = barriers / set-up only, 3 = epilogue only, 32+3 = epilogue without its stores
     for (int abl : {0, 8, 9, 10, 11, 3, 32 + 3}) run<128, 128, 2, 2, 2>(p, abl, secs, "128x128x2");
     for (int abl : {0, 8, 9, 10, 11, 3, 32 + 3}) run<256, 256, 2, 4, 2>(p, abl, secs, "256x256x2");
-    for (int pers : {0, 1})
-        for (int nt : {0, 1}) {
-            g_persist = pers; p.st_nt = nt;
-            char tag[64];
-            snprintf(tag, sizeof tag, "128x128x2 persist=%d nt=%d", pers, nt); run<128, 128, 2, 2, 2>(p, 0, secs, tag);
-            snprintf(tag, sizeof tag, "256x256x2 persist=%d nt=%d", pers, nt); run<256, 256, 2, 4, 2>(p, 0, secs, tag);
-        }
+    p.st_nt = 1;
+    run<128, 128, 2, 2, 2>(p, 0, secs, "128x128x2 non-temporal stores");
+    run<256, 256, 2, 4, 2>(p, 0, secs, "256x256x2 non-temporal stores");
+    p.st_nt = 0;
     printf("GF %.1f\n", gf);
     return 0;
 }
