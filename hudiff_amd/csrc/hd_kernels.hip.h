@@ -209,6 +209,23 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // with 16-B stores and (optionally) leaves the LayerNorm slice partials of the rows it wrote.
 // smem must hold NW * 32 * (BN/WN + 4) + NW * (BM/WM) * 2 floats (NW = WM * WN waves) and be free (all waves past their
 // last LDS read).
+// (hi, lo) fp16 split of four fp32 values, hi = fp16(x), lo = fp16(x - hi): two packed conversions for the high parts and one
+// v_fma_mix{lo,hi}_f16 per low part (fp16 operand hi, fp32 operand x, fp16 result: x - hi is exact in fp32, so the single
+// rounding is the one the conversion would commit) -- 6 instructions where convert / convert back / subtract / convert takes 14;
+// bit-identical on 16 M random bit patterns incl. fp16 subnormals (checked on the device when this was introduced).
+typedef _Float16 hd_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    hh = __builtin_convertvector(v, hd_f16x4);
+    const u32x2_t h = __builtin_bit_cast(u32x2_t, hh);
+    u32x2_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[0]) : "v"(h[0]), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[0]) : "v"(h[0]), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[1]) : "v"(h[1]), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[1]) : "v"(h[1]), "v"(v[3]));
+    ll = __builtin_bit_cast(hd_f16x4, l);
+}
+
 // F: the epilogue features that MAY be present (each is still tested at run time); a caller that knows a launch uses only a few
 // of them instantiates the epilogue with those bits, and the code of the others -- their descriptors, scalar loads and
 // branches, 35 % of the vector-ALU instructions of a plain launch -- is not compiled in.  gemm_x3_k picks the smallest of a
@@ -346,8 +363,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
                 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                const h16x4 hh = __builtin_convertvector(v, h16x4);
-                const h16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), h16x4);
+                h16x4 hh, ll;
+                split4(v, hh, ll);
                 float* base = c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
                 const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
@@ -1008,8 +1025,8 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                 f32x4 w;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[k] = act_f((v[j][k] - mean) * rstd * gv[k] + bv[k], act);
-                const f16x4 hh = __builtin_convertvector(w, f16x4);
-                const f16x4 ll = __builtin_convertvector(w - __builtin_convertvector(hh, f32x4), f16x4);
+                f16x4 hh, ll;
+                split4(w, hh, ll);
                 *reinterpret_cast<f16x4*>(yh + c) = hh;
                 *reinterpret_cast<f16x4*>(yh + C + c) = ll;
             }
@@ -1383,8 +1400,8 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                 o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
                 const int col = h * ATT_HD + 16 * dt + 4 * g;
                 if (o_split) {                         // split rows for the out-projection's gemm_x3_k (ldo halfs hi, then lo)
-                    const f16x4 hh = __builtin_convertvector(o, f16x4);
-                    const f16x4 ll = __builtin_convertvector(o - __builtin_convertvector(hh, f32x4), f16x4);
+                    f16x4 hh, ll;
+                    split4(o, hh, ll);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
                     *reinterpret_cast<f16x4*>(orow + col) = hh;
                     *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
@@ -1487,8 +1504,8 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
                 kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
                 if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
-                const f16x4 hh = __builtin_convertvector(kr, f16x4);
-                const f16x4 ll = __builtin_convertvector(kr - __builtin_convertvector(hh, f32x4), f16x4);
+                f16x4 hh, ll;
+                split4(kr, hh, ll);
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
                 *reinterpret_cast<f16x4*>(Kh + off) = hh;
                 *reinterpret_cast<f16x4*>(Kl + off) = ll;
@@ -1501,11 +1518,18 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
             const int t = c >> 2, g = c & 3;
             f16x8 hh, ll;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
-                const float x = key < L ? vv[cc][j] : 0.f;
-                const _Float16 xh = (_Float16)x;
-                hh[j] = xh; ll[j] = (_Float16)(x - (float)xh);
+            for (int q4 = 0; q4 < 2; ++q4) {
+                f32x4 x4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * q4 + e;
+                    const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
+                    x4[e] = key < L ? vv[cc][j] : 0.f;
+                }
+                f16x4 h4, l4;
+                split4(x4, h4, l4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hh[4 * q4 + e] = h4[e]; ll[4 * q4 + e] = l4[e]; }
             }
             const int off = lane * (AX_VKEYS * 2) + (G::vpos(c, lane) << 4);
             *reinterpret_cast<f16x8*>(Vh + off) = hh;
@@ -1536,8 +1560,8 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 f32x4 r;
                 r[0] = (v[0] * cs.x - v[1] * sn.x) * QS; r[1] = (v[0] * sn.x + v[1] * cs.x) * QS;
                 r[2] = (v[2] * cs.y - v[3] * sn.y) * QS; r[3] = (v[2] * sn.y + v[3] * cs.y) * QS;
-                const f16x4 hh = __builtin_convertvector(r, f16x4);
-                const f16x4 ll = __builtin_convertvector(r - __builtin_convertvector(hh, f32x4), f16x4);
+                f16x4 hh, ll;
+                split4(r, hh, ll);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { qh[ks][4 * hf + e] = hh[e]; ql[ks][4 * hf + e] = ll[e]; }
             }
@@ -1596,10 +1620,11 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         for (int t = 0; t < (AX_KT + 1) / 2; ++t) {
             f16x8 ph, pl;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = st[2 * t + (j >> 2)][j & 3];
-                const _Float16 xh = (_Float16)x;
-                ph[j] = xh; pl[j] = (_Float16)(x - (float)xh);
+            for (int q4 = 0; q4 < 2; ++q4) {
+                f16x4 h4, l4;
+                split4(st[2 * t + q4], h4, l4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ph[4 * q4 + e] = h4[e]; pl[4 * q4 + e] = l4[e]; }
             }
             const int c = 4 * t + g;
             const int co = G::vpos(c, qi) << 4;        // rows 16 dt + qi: 16 dt touches neither bits 1..3 nor bits 2..3 of the row
@@ -1620,8 +1645,8 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
                 const int col = h * ATT_HD + 16 * dt + 4 * g;
                 if (o_split) {
-                    const f16x4 hh = __builtin_convertvector(o, f16x4);
-                    const f16x4 ll = __builtin_convertvector(o - __builtin_convertvector(hh, f32x4), f16x4);
+                    f16x4 hh, ll;
+                    split4(o, hh, ll);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
                     *reinterpret_cast<f16x4*>(orow + col) = hh;
                     *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
