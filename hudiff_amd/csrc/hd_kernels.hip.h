@@ -1542,6 +1542,16 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
     const int sw = (qi >> 1) & 7;                      // swizzle of this lane's K row (rows 16 kt + qi)
     const int sw_last = ((L - 1) >> 1) & 7;            // ... and of row L - 1, which stands in for keys >= L
     const int nqt = (L + 15) / 16;
+    // V^T fragment of step t (keys 32 t ..), d tile dt: chunk 4 t + g of row 16 dt + qi.  Its swizzled position is
+    // 8 (t >> 1) + a lane term that depends on t only through its parity, so two lane-constant bases per plane and
+    // compile-time offsets (128 (t >> 1) + dt x 16 rows) address every read: no vector-ALU address arithmetic in the PV loop.
+    const char* vph[2];
+    const char* vpl[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        vph[par] = Vh + qi * (AX_VKEYS * 2) + (G::vpos(4 * par + g, qi) << 4);
+        vpl[par] = vph[par] + AX_VPLANE;
+    }
     for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
@@ -1598,10 +1608,17 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         float mx = -INFINITY, sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < AX_KT; ++kt)
+            {
+                // the launcher guarantees 16 (KT - 1) < L <= 16 KT: keys >= L exist only in the last tile, and only there are the
+                // scores compared / selected (with L unconstrained the compiler parks 76 lane masks in spilled SGPRs: 240 of the
+                // 870 vector instructions per query tile were v_readlane / v_cndmask)
+                if (kt == AX_KT - 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;       // compile-time false except in the last tiles
-                mx = fmaxf(mx, st[kt][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + 4 * g + r >= L) st[kt][r] = -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -1626,12 +1643,10 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ph[4 * q4 + e] = h4[e]; pl[4 * q4 + e] = l4[e]; }
             }
-            const int c = 4 * t + g;
-            const int co = G::vpos(c, qi) << 4;        // rows 16 dt + qi: 16 dt touches neither bits 1..3 nor bits 2..3 of the row
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int ro = (16 * dt + qi) * (AX_VKEYS * 2) + co;
-                const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + ro), vl = *reinterpret_cast<const f16x8*>(Vl + ro);
+                const int ro = 128 * (t >> 1) + 16 * dt * (AX_VKEYS * 2);          // compile-time (t, dt unrolled)
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vph[t & 1] + ro), vl = *reinterpret_cast<const f16x8*>(vpl[t & 1] + ro);
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[dt], 0, 0, 0);
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[dt], 0, 0, 0);
