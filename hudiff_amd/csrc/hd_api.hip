@@ -993,9 +993,11 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
     // attn_x3_k<KT> masks only its last key tile: 16 (KT - 1) < L <= 16 KT (291 and 152 qualify); other lengths keep attn_k
-    if (x3 && ax_on && m->L > 16 * 18 && m->L <= 16 * 19)
+    // ... and address QKV with 32-bit byte offsets
+    const bool ax_ok = x3 && ax_on && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
         hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
-    else if (x3 && ax_on && m->L > 16 * 9 && m->L <= 16 * 10) {
+    else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
         hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
     } else if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);

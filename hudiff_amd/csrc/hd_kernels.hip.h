@@ -1463,8 +1463,18 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
     char* Vh = axs + 2 * krows * 128;
     char* Vl = Vh + AX_VPLANE;
     const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
+    // activation row of key slot s of this sequence = s + (s >= off[1] ? A1 : A0); byte offsets inside QKV are 32-bit (the launcher
+    // checks rows x ldq x 4 < 2 GiB), loads go through buffer descriptors: ~6 vector instructions of addressing per K load and
+    // none per V load (its row is wave-uniform -> scalar offset) instead of the 14 of 64-bit pointer arithmetic.
+    const int rA0 = sg.base[0] + b * sg.len[0] - sg.off[0];
+    const int rA1 = sg.nseg > 1 ? sg.base[1] + b * sg.len[1] - sg.off[1] : rA0;
+    const int roff1 = sg.nseg > 1 ? sg.off[1] : 0x7fffffff;
+    const uint32_t rowb = (uint32_t)ldq * 4u;
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_cos), 0, L * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_sin), 0, L * 128, 0x00020000);
 
     // ---- stage K (rotate, split, swizzled 8-byte writes; keys >= L are zero rows) and V^T (a wave takes 8-key chunks,
     //      lane = d: 8 row loads of 256 B each, two 16-byte writes).  Every global load of both is issued before the first
@@ -1476,22 +1486,26 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         f32x4 kb[NST];
         float2 cb[NST], sb[NST];
         float vv[NCH][8];
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const int kcol = (koff + (tid & 15) * 4) * 4, rcol = (tid & 15) * 8;              // byte offsets inside a row
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int idx = tid + ATT_THREADS * k;
-            const int key = min(idx >> 4, L - 1), c4 = (idx & 15) * 4;
-            kb[k] = *reinterpret_cast<const f32x4*>(QKV + (long)sg.row(b, key) * ldq + koff + c4);
-            cb[k] = *reinterpret_cast<const float2*>(rope_cos + key * 32 + (c4 >> 1));
-            sb[k] = *reinterpret_cast<const float2*>(rope_sin + key * 32 + (c4 >> 1));
+            const int key = min((tid >> 4) + (ATT_THREADS / 16) * k, L - 1);
+            const int row = key + (key >= roff1 ? rA1 : rA0);
+            kb[k] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(q_rs, (int)((uint32_t)row * rowb + (uint32_t)kcol), 0, 0));
+            cb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(c_rs, key * 128 + rcol, 0, 0));
+            sb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(s_rs, key * 128 + rcol, 0, 0));
         }
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) {
-            const int c = min(wave + (ATT_THREADS / 64) * cc, NCHUNK - 1);            // chunk 4 t + g
+            const int c = min(wave + (ATT_THREADS / 64) * cc, NCHUNK - 1);            // chunk 4 t + g (wave-uniform)
             const int t = c >> 2, g = c & 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
-                vv[cc][j] = QKV[(long)sg.row(b, min(key, L - 1)) * ldq + voff + lane];
+                const int key = min(32 * t + 16 * (j >> 2) + 4 * g + (j & 3), L - 1);
+                const int row = key + (key >= roff1 ? rA1 : rA0);                       // scalar
+                vv[cc][j] = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(q_rs, (voff + lane) * 4, (int)((uint32_t)row * rowb), 0));
             }
         }
 #pragma unroll
