@@ -996,6 +996,17 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                                                    int act, int split_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    // the row itself is requested before the statistics are merged (the pass is bound by load round trips, not bandwidth:
+    // one row per wave, two dependent trips otherwise)
+    f32x4 v[4];
+    if (split_out) {
+        const float* x0 = X + (long)row * ldx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < C) v[j] = *reinterpret_cast<const f32x4*>(x0 + c);
+        }
+    }
     float mean, rstd;
     if (stats) {
         const float2 st = stats[row];
@@ -1010,12 +1021,6 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
     const float* x = X + (long)row * ldx;
     float* y = Y + (long)row * ldy;
     if (split_out) {                                   // C <= 1024
-        f32x4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (c < C) v[j] = *reinterpret_cast<const f32x4*>(x + c);
-        }
         _Float16* yh = reinterpret_cast<_Float16*>(y);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
