@@ -767,7 +767,24 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(256);
     // 0 none (also a LayerNorm folded into the weights, p.ln_fold), 1 LN, 2 LN+ReLU, 3 LN+GELU
     const int pro = (!q.ln_fold && (q.stats || q.spart)) ? 1 + q.pro_act : 0;
-#define HD_LAUNCH(CONV, PRO) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, NB, BKT>), grid, blk, 0, st, q)
+    // epilogue feature mask (hd_kernels.hip.h, gemm_epilogue): the hot shapes exist in four instantiations -- tap GEMM / PFF1
+    // (LayerNorm partials only), Q|K|V and FF1 (folded LayerNorm, activation), out-projection / FF2 (residual, partials), everything --
+    // and a launch takes the smallest that covers it; the other shapes carry the full epilogue
+    constexpr bool HOT = BKT == 16 && NB == 1 && BM >= 64;
+    const int need = epi_needs(q);
+    const int mask = !HOT ? 3 : !(need & ~EPI_PART) ? 0 : !(need & ~(EPI_FOLD | EPI_ACT)) ? 1 : !(need & ~(EPI_RESID | EPI_PART)) ? 2 : 3;
+#define HD_LAUNCH_E(CONV, PRO, E) hipLaunchKernelGGL((gemm_k<BM, BN, WM, WN, CONV, PRO, 0, NB, BKT, E>), grid, blk, 0, st, q)
+#define HD_LAUNCH(CONV, PRO)                                                                       \
+    do {                                                                                           \
+        if constexpr (HOT) {                                                                       \
+            if (mask == 0) HD_LAUNCH_E(CONV, PRO, EPI_PART);                                       \
+            else if (mask == 1) HD_LAUNCH_E(CONV, PRO, EPI_FOLD | EPI_ACT);                        \
+            else if (mask == 2) HD_LAUNCH_E(CONV, PRO, EPI_RESID | EPI_PART);                      \
+            else HD_LAUNCH_E(CONV, PRO, EPI_ALL);                                                  \
+        } else {                                                                                   \
+            HD_LAUNCH_E(CONV, PRO, EPI_ALL);                                                       \
+        }                                                                                          \
+    } while (0)
     if (!conv) {
         switch (pro) {
             case 0: HD_LAUNCH(false, 0); break;
@@ -784,6 +801,7 @@ static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
     }
 }
 #undef HD_LAUNCH
+#undef HD_LAUNCH_E
 
 // p.part != nullptr: the epilogue leaves LayerNorm partials of the output rows and they are merged into `stats_out`.
 struct LnApply { const float* gamma = nullptr; const float* beta = nullptr; int k_stride = 0; int act = 0; int split = 0; };

@@ -234,7 +234,7 @@ __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll
 enum : int { EPI_FOLD = 1, EPI_ACT = 2, EPI_RESID = 4, EPI_DROP = 8, EPI_EXTRA = 16, EPI_PART = 32, EPI_CSPLIT = 64, EPI_C2 = 128,
              EPI_ALL = 255,
              EPI_X3 = 256 };      // set by gemm_x3_k on every mask: acc_scale always applies, stores are non-temporal
-__device__ __forceinline__ int epi_needs(const GemmP& p) {
+__host__ __device__ __forceinline__ int epi_needs(const GemmP& p) {
     return (p.ln_fold ? EPI_FOLD : 0) | (p.epi_act ? EPI_ACT : 0) | (p.resid ? EPI_RESID : 0) | (p.drop_mode != DROP_NONE ? EPI_DROP : 0) |
            (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0);
 }
@@ -436,7 +436,7 @@ __device__ __forceinline__ float2 gemm_row_stat(const GemmP& p, long grow) {
 //   Epilogue: each wave transposes its accumulators through its own slice of the (now free) LDS so that
 //     every lane owns 4 consecutive columns of one row: bias / activation / residual / dropout / addend are
 //     applied on float4s and written with 16-B stores (4 rows x 256 B per wave instruction).
-template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool CONV, int PRO, int ABLATE = 0, int NBUF = 1, int BK = 32, int EPI = EPI_ALL>
 __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_k(const GemmP p) {
     constexpr int KQ = BK / 4;                        // float4 per A row per k tile
     // BK == 16 kernels are launched only when Kc % 16 == 0 and every operand spans < 4 GiB (host-checked): their K
@@ -732,9 +732,9 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     }
     if (NBUF == 2) __syncthreads();
 
-    // (feature-masked epilogue instantiations as in gemm_x3_k were tried here: four copies of the epilogue behind a branch push this
-    // 128-VGPR kernel into scratch -- 600 spilled registers, half the speed -- and the epilogue is < 10 % of its time anyway)
-    gemm_epilogue<BM, BN, WM, WN>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
+    // EPI: the epilogue features this instantiation carries (chosen by the host, launch_gemm_t: one epilogue per kernel -- four
+    // copies behind an in-kernel branch, as gemm_x3_k has them, push this 128-VGPR kernel into scratch: 600 spilled registers)
+    gemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
 
