@@ -10,9 +10,9 @@ static float run(const float* QKV, const float* rc, const float* rs, float* O, S
     hipFuncSetAttribute((const void*)attn_k<19, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     dim3 grid(sg.B * nhead);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((attn_k<19, ABL>), grid, dim3(ATT_THREADS), smem, 0, QKV, 3 * A, A, rc, rs, O, A, nhead, sg);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((attn_k<19, ABL>), grid, dim3(ATT_THREADS), smem, 0, QKV, 3 * A, A, rc, rs, O, A, nhead, sg, 0);
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((attn_k<19, ABL>), grid, dim3(ATT_THREADS), smem, 0, QKV, 3 * A, A, rc, rs, O, A, nhead, sg);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((attn_k<19, ABL>), grid, dim3(ATT_THREADS), smem, 0, QKV, 3 * A, A, rc, rs, O, A, nhead, sg, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms / iters * 1e3f;
