@@ -322,3 +322,24 @@ def test_fasta_reader_and_single_molecule_helpers(tmp_path):
     assert open(os.path.join(d, "0_human.fasta")).read().splitlines()[0] == ">0_human_H <unknown description>"
     assert open(os.path.join(d, "1_human.fasta")).read().splitlines() == [">1_human_H VH", vh, ">1_human_L VL", vl]
     assert os.path.isdir(tmp_path / "log" / "sample_human_pdb")
+
+
+def test_bench_clock_power_sampler_is_optional():
+    """bench.py samples shader clock / package power from the amdgpu hwmon files of the GPU it runs on; where there is no
+    such device (this container) the sampler must be inert: no thread, no exception, `None` in the JSON line."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    s = mod.ClockPowerSampler(0)
+    if s.dir is None:                       # no GPU / no hwmon: inert
+        assert s.start() is s and s.stop() is None
+    else:                                   # on a GPU box: a short window yields a dict with the documented keys
+        import time
+        s.start(); time.sleep(0.35)
+        out = s.stop()
+        assert out is None or {"sclk_mhz_median", "power_w_median", "samples"} <= set(out)
+    phys, logical = mod.physical_cores()
+    assert 1 <= phys <= logical
