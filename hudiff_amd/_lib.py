@@ -17,7 +17,7 @@ HD_ABI_VERSION = 1
 HD_KIND_ANTIBODY, HD_KIND_NANOBODY = 0, 1
 HD_ACT_RELU, HD_ACT_GELU = 1, 2
 HD_DROPOUT_FAITHFUL, HD_DROPOUT_OFF, HD_DROPOUT_INJECT, HD_NO_GRAPH, HD_NO_PRUNE, HD_ONE_LANE, HD_LOOP_GRAPH = 0, 1, 2, 4, 8, 16, 32
-HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_DEVICE = range(6)
+HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_DEVICE, HD_ERR_NUMERIC = range(7)
 
 EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",

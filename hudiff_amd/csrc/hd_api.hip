@@ -1463,6 +1463,13 @@ extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
     }
     for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
     m->cl = 0;
+    for (int l = 0; l < m->nlanes; ++l) {
+        RunState h{};
+        HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
+        if (h.pad[0])
+            return fail(HD_ERR_NUMERIC, "hd_sample: non-finite logits (NaN / inf) at some denoiser step -- weights or inputs out of range; "
+                                        "the reference's torch.multinomial raises at this point");
+    }
     return HD_OK;
 }
 

@@ -53,7 +53,7 @@ struct RunState {
     uint32_t step;
     uint32_t seed_lo, seed_hi;
     uint32_t row0;
-    uint32_t pad[4];
+    uint32_t pad[4];       // pad[0]: set by sample_step_k when a visited row had non-finite logits
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1928,7 +1928,11 @@ __global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm
     }
     const float mx = wave_max(mylogit);
     const float e = (lane < 22) ? expf(mylogit - mx) : 0.f;
-    const float p = e / wave_sum(e);
+    const float esum = wave_sum(e);
+    // a NaN / infinite logit makes the sum NaN (the reference's torch.multinomial raises on such a row, sample.py:512); the
+    // step still writes a token, hd_sample_end reports the flag
+    if (lane == 0 && !(esum > 0.f && esum < INFINITY)) atomicOr(const_cast<uint32_t*>(&rs->pad[0]), 1u);
+    const float p = e / esum;
     float q = 1.f;
     if (lane < 22) {
         if (q_noise) {

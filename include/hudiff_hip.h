@@ -55,7 +55,9 @@ typedef enum HdStatus {
     HD_ERR_UNSUPPORTED = 2,  /* configuration outside what the kernels implement                 */
     HD_ERR_STATE = 3,        /* call order (e.g. forward before finalize, missing tensors)       */
     HD_ERR_HIP = 4,          /* a HIP runtime call failed; message has the hipError string       */
-    HD_ERR_NO_DEVICE = 5     /* no usable gfx950 device: the product path never falls back to CPU */
+    HD_ERR_NO_DEVICE = 5,    /* no usable gfx950 device: the product path never falls back to CPU */
+    HD_ERR_NUMERIC = 6       /* hd_sample / hd_sample_end: a visited row had NaN / infinite logits at some step (the
+                                reference's torch.multinomial raises there, sample.py:512); tokens are still returned */
 } HdStatus;
 
 enum { HD_KIND_ANTIBODY = 0, HD_KIND_NANOBODY = 1 };

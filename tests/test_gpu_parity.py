@@ -224,6 +224,27 @@ def test_empty_batch_and_errors(micro, hip):
             m(z["tokens"], z["region"], np.array([0, 0, 2, 2, 2, 2]))
 
 
+def test_non_finite_logits_are_reported(micro, hip):
+    """A NaN in the weights makes every logit NaN; the reference's loop dies in torch.multinomial (sample.py:512).  Here the
+    sample runs to the end (tokens are written) and hd_sample reports HD_ERR_NUMERIC; a healthy model on the same handle
+    type is unaffected, and a session's flag is cleared by the next hd_sample_begin."""
+    from hudiff_amd import synthetic as S
+    from hudiff_amd._lib import HD_ERR_NUMERIC, HudiffError
+    sd = {k: np.array(v, copy=True) for k, v in micro["sd"].items()}
+    sd["decoder.weight"][3, 0] = np.nan
+    bad = _mk(hip, micro["kind"], micro["cfg"], sd)
+    try:
+        batch = S.synthetic_batch(micro["kind"], 3, seed=5)
+        T = np.minimum(batch["T"], 2)
+        with pytest.raises(HudiffError) as e:
+            bad.sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=1)
+        assert e.value.status == HD_ERR_NUMERIC
+        good = micro["m0"].sample(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=1)
+        assert ((good >= 0) & (good <= 22)).all()
+    finally:
+        bad.close()
+
+
 @pytest.mark.parametrize("kind", ["ab", "nb"])
 def test_deep_golden_vs_reference(hip, kind):
     """Production depth and head structure (6 + 6 ByteNet blocks = dilations 1..32, 5 SelfAttBlocks, 8 heads) at small
