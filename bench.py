@@ -211,21 +211,21 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
                       f"mean T = {mean_T:.1f} steps per sequence"}
 
 
-def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows):
+def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows, env_name="HUDIFF_X3"):
     """The same workload on the split-precision GEMM kernels (HUDIFF_X3=1: three fp16 MFMAs with fp32 accumulation per fp32
     product, hd_kernels.hip.h gemm_x3_k).  Reported BESIDE the metric, never as it: the f32 line above is the product path."""
     import hudiff_amd
     B = args.batch
-    prev = os.environ.get("HUDIFF_X3")
-    os.environ["HUDIFF_X3"] = "1"
+    prev = os.environ.get(env_name)
+    os.environ[env_name] = "1"
     try:
         model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
         model.load_state_dict(sd)
     finally:
         if prev is None:
-            os.environ.pop("HUDIFF_X3", None)
+            os.environ.pop(env_name, None)
         else:
-            os.environ["HUDIFF_X3"] = prev
+            os.environ[env_name] = prev
     ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
     logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
     dmax = float(np.abs(logits - ref_logits).max())
@@ -392,6 +392,13 @@ def main():
                            row0=rank * B, step=0)
         x3_tokens, split = split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows)
         split["rows_with_identical_tokens"] = f"{int((x3_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)"
+        # for the record: the fp32 GEMMs with ONLY the attention kernel in split precision (HUDIFF_ATTN_X3=1)
+        ao_tokens, ao = split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows,
+                                            env_name="HUDIFF_ATTN_X3")
+        split["attention_kernel_only"] = {
+            "value": ao["value"], "unit": "sequences/s", "steps": ao["steps"], "max_abs_dlogit_vs_f32_path": ao["max_abs_dlogit_vs_f32_path"],
+            "rows_with_identical_tokens": f"{int((ao_tokens == tokens).all(1).sum())} of {B}",
+            "note": "fp32 GEMMs + attn_x3_k (HUDIFF_ATTN_X3=1); not the metric"}
 
     # ---- the single collective of the job: gather the final tokens on rank 0 (RCCL over xGMI) ----------
     gathered = [tokens]

@@ -111,6 +111,7 @@ struct HdModel {
     float* blob = nullptr;
     uint16_t* blobx = nullptr;        // split-precision copies of the GEMM weights (HUDIFF_X3=1 at hd_finalize)
     bool x3 = false;
+    bool attn_x3 = false;                            // HUDIFF_ATTN_X3=1 at hd_finalize: split-precision attention kernel inside the fp32 path
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
     std::vector<AttBlockW> att;
@@ -492,6 +493,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     Packer pk;
     X3Packer xpk;
     { const char* e = getenv("HUDIFF_X3"); m->x3 = e && atoi(e) != 0; }
+    { const char* e = getenv("HUDIFF_ATTN_X3"); m->attn_x3 = e && atoi(e) == 1; }
     X3Packer* xp = m->x3 ? &xpk : nullptr;
     // HUDIFF_X3_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
     const int x3_mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 3; }();
@@ -663,12 +665,11 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         HIP_TRY(hipGetLastError());
     }
     const size_t smem = (size_t)L * (ATT_KS + att_vs(L > 160 ? 19 : 10)) * sizeof(float);
+    // (a split-precision model still runs the fp32 attention kernel for launches too small for the split kernels)
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (m->x3) {
-        HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<19>::SMEM));
-        HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<10>::SMEM));
-    }
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<19>::SMEM));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<10>::SMEM));
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
     m->finalized = true;
@@ -1012,11 +1013,14 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
     // attn_x3_k<KT> masks only its last key tile: 16 (KT - 1) < L <= 16 KT (291 and 152 qualify); other lengths keep attn_k
     // ... and address QKV with 32-bit byte offsets
-    const bool ax_ok = x3 && ax_on && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    // HUDIFF_ATTN_X3=1 (read at hd_finalize): the split-precision attention kernel inside the fp32 path as well (fp32 Q|K|V in, fp32 O out); an
+    // experiment for the record, off by default: the product path computes in fp32 throughout
+    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    const int osp = x3 ? 1 : 0;
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
-        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp);
     else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
-        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, 1);
+        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp);
     } else if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
     else
