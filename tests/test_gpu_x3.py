@@ -171,3 +171,37 @@ def test_x3_feature_masked_epilogues_change_nothing(hip, tmp_path):
     finally:
         m32.close(); mx3.close()
     assert np.array_equal(np.load(out), here)
+
+
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_split_attention_kernel_inside_the_fp32_path(hip, kind):
+    """HUDIFF_ATTN_X3=1 at hd_finalize: fp32 GEMMs with attn_x3_k in place of attn_k (fp32 Q|K|V in, fp32 O out).  Logits within
+    1e-4 of the all-fp32 kernels' (observed ~1e-6) and the same tokens on complete short samples."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    sd = S.random_state_dict(kind, cfg, seed=0)
+    cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
+    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
+    try:
+        os.environ["HUDIFF_X3"] = "0"
+        os.environ.pop("HUDIFF_ATTN_X3", None)
+        m32 = cls(**cfg); m32.load_state_dict(sd)
+        os.environ["HUDIFF_ATTN_X3"] = "1"
+        mat = cls(**cfg); mat.load_state_dict(sd)
+    finally:
+        for k, v in prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    try:
+        B = 64 if kind == "ab" else 128
+        batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
+        kw = dict(dropout="faithful", seed=3, row0=0, step=2)
+        a = m32(batch["tokens"], batch["region"], batch["chain"], **kw)
+        b = mat(batch["tokens"], batch["region"], batch["chain"], **kw)
+        d = float(np.abs(a - b).max())
+        assert 0.0 < d < LOGIT_TOL, d                      # the other kernel really ran, and agrees
+        T4 = np.minimum(batch["T"], 4)
+        args = (batch["tokens"], batch["region"], batch["chain"], batch["order"], T4)
+        assert np.array_equal(m32.sample(*args, seed=11, row0=0), mat.sample(*args, seed=11, row0=0))
+    finally:
+        m32.close(); mat.close()
