@@ -8,7 +8,7 @@
 A "step" is one complete T-step humanization sample of one batch of B = 256 independent rows per GPU
 (BASELINE.json configs[1]: HuDiff-Ab on HuAb348, batch 256, 1 x MI355X): up to 154 denoiser forwards of the
 39.8 M-parameter AntiTFNet over 291 slots + the exponential-race resampling, with inference-time dropout as
-the reference runs it.  Rows are the 348 HuAb348 mouse pairs (pre-slotted integer fixture tests/golden/real_rows.npz,
+the reference runs it.  Rows are the 348 HuAb348 mouse pairs (pre-slotted integer fixture hudiff_amd/data/real_rows.npz,
 scripts/make_real_rows.py; global row g = pair g % 348, replica g // 348, ragged T = 141..154) -- `--data synthetic`
 gives the HuAb348-shaped random rows of round 1 instead.  Weights are seeded random weights of the exact production
 architecture (no released checkpoint offline).  Rows shard across GPUs with no data-path collective; one RCCL gather
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--max-t", type=int, default=0, help="truncate every row to this many denoiser steps "
                     "(profiling aid; the JSON line is then marked truncated and is NOT the metric)")
     ap.add_argument("--data", choices=["auto", "real", "synthetic"], default="auto",
-                    help="real = rows of the reference's evaluation set (HuAb348 / VHH, tests/golden/real_rows.npz); "
+                    help="real = rows of the reference's evaluation set (HuAb348 / VHH, hudiff_amd/data/real_rows.npz); "
                          "auto = real when the fixture is present")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the 'best batch' CPU leg (B = 1 is always timed too)")
@@ -306,21 +306,52 @@ def live_traffic(args, kind, mode, n_steps=4):
                     "Infinity-Cache hits included"}
 
 
+def relaunch_one_rank_per_gpu(args):
+    """`python bench.py --gpus N` without a launcher around it (the driver's single-node command shape): start N ranks of
+    this very command under torch.distributed.run -- one process per GPU, rendezvous on 127.0.0.1 -- and hand back its exit
+    code.  Rank 0 of that job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_one_rank_per_gpu(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never print a line whose n_gpus is not what was asked for
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     # Debug aid for single-GPU boxes: HUDIFF_BENCH_SHARE_GPU=1 runs every rank on device 0 with a gloo (CPU)
     # gather, so that the N > 1 control flow can be exercised without N GPUs.  Never set by the driver.
     share_gpu = os.environ.get("HUDIFF_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
-    if world > 1:
+    # HUDIFF_BENCH_FORCE_PG=1: form the RCCL process group even for one rank (a world-size-1 nccl group is legal), so that
+    # the communicator init, the device-tensor gather and the all-reduce below run on a one-GPU box (tests/test_gpu_dist.py)
+    force_pg = os.environ.get("HUDIFF_BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if force_pg and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -430,7 +461,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": (("HuAb348 mouse pairs" if kind == "ab" else "abnativ_select_vhh VHH") +
                      f" ({batch['n_sequences']} sequences of the reference's evaluation CSV, IMGT-slotted by hudiff_amd.numbering into "
-                     "tests/golden/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
+                     "hudiff_amd/data/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
             if real else "synthetic",
             "config": {"workload": (("HuDiff-Ab AntiTFNet (39.8M params, L=291) on HuAb348, " if real else
                                      "HuDiff-Ab AntiTFNet (39.8M params, L=291), HuAb348-shaped synthetic rows, ")

@@ -60,25 +60,48 @@ def EasyDict(*a, **k):
 
 _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
                   "complex", "slice", "range", "object"}
-_SAFE_EXACT = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("easydict", "EasyDict"),
-               ("numpy", "dtype"), ("numpy", "ndarray"), ("_codecs", "encode"), ("argparse", "Namespace")}
-_SAFE_MODULES = ("torch._utils", "torch._tensor", "torch.storage", "torch.serialization", "torch.nn.parameter",
-                 "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric",
-                 "numpy.dtypes")
+# EXACT (module, name) pairs only.  No whole module is admitted: torch.storage._load_from_bytes is torch.load(weights_only=False)
+# on an embedded byte string -- an unrestricted nested unpickle -- and torch.serialization.load / torch._utils helpers that
+# take a callable are similar gadgets.  What a state_dict + config pickle really names is this short list.
+_SAFE_EXACT = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("easydict", "EasyDict"), ("argparse", "Namespace"),
+    ("_codecs", "encode"),
+    # tensors: torch.save writes _rebuild_tensor_v2(storage, offset, size, stride, requires_grad, hooks) (+ _rebuild_parameter for
+    # nn.Parameter values); the storages themselves arrive through persistent_load, which names only a torch.*Storage class
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch.nn.parameter", "Parameter"), ("torch.storage", "TypedStorage"), ("torch.storage", "UntypedStorage"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    # numpy scalars / arrays inside configs (iteration counters, loss values)
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy.core.multiarray", "scalar"), ("numpy.core.multiarray", "_reconstruct"),
+    ("numpy._core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+}
+_TORCH_DTYPE_PREFIXES = ("float", "int", "uint", "bfloat", "complex", "bool", "double", "half", "long", "short")
+
+
+def _allowed(module, name):
+    if module == "builtins":
+        return name in _SAFE_BUILTINS
+    if (module, name) in _SAFE_EXACT:
+        return True
+    if module == "torch":          # torch.FloatStorage & co (legacy typed-storage classes), torch.float32 & co (dtype singletons)
+        return (name.endswith("Storage") and name[0].isupper() and name.isidentifier()) or \
+            (name.startswith(_TORCH_DTYPE_PREFIXES) and name.replace("_", "").isalnum() and name.islower())
+    if module == "numpy.dtypes":   # numpy >= 2 pickles dtype classes by name (Float64DType, ...)
+        return name.endswith("DType") and name.isidentifier()
+    return False
 
 
 def _restricted_pickle_module():
     """A ``pickle_module`` for torch.load whose Unpickler resolves only tensor-rebuilding helpers, plain containers
-    and EasyDict: a checkpoint cannot name os.system / builtins.eval / arbitrary classes.  (torch's own
-    ``weights_only=True`` unpickler cannot be used: it refuses to fill dict subclasses such as EasyDict.)"""
+    and EasyDict -- an exact (module, name) allow-list: a checkpoint cannot name os.system / builtins.eval / arbitrary
+    classes, nor torch.storage._load_from_bytes (a nested unrestricted unpickle).  (torch's own ``weights_only=True``
+    unpickler cannot be used: it refuses to fill dict subclasses such as EasyDict.)"""
     import pickle
 
     class RestrictedUnpickler(pickle.Unpickler):
         def find_class(self, module, name):
-            ok = (module == "builtins" and name in _SAFE_BUILTINS) or (module, name) in _SAFE_EXACT or \
-                module in _SAFE_MODULES or (module == "torch" and (name.endswith("Storage") or name in ("Size", "device", "dtype")
-                                                                    or name.startswith(("float", "int", "uint", "bfloat", "complex", "bool"))))
-            if not ok:
+            if not _allowed(module, name):
                 raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is outside the allow-list")
             return super().find_class(module, name)
 
@@ -95,8 +118,10 @@ def _restricted_pickle_module():
 def load_checkpoint(path, map_location="cpu", trust_pickle=None):
     """torch.load(path) tolerant of EasyDict configs.
 
-    The file is read through a restricted unpickler (tensors, plain containers, numpy scalars and
-    ``easydict.EasyDict`` only), so that a ``--ckpt`` from an untrusted source cannot run code.  A checkpoint that
+    The file is read through a restricted unpickler (an exact allow-list of tensor-rebuilding helpers, plain containers,
+    numpy scalars and ``easydict.EasyDict``), so that a ``--ckpt`` from an untrusted source cannot name a callable of its
+    choosing (tests/test_host_logic.py drives the known gadgets -- os / builtins callables, torch.storage._load_from_bytes,
+    torch.serialization.load -- through it).  A checkpoint that
     carries other pickled classes needs the unrestricted loader, which executes whatever the pickle says: opt in
     with ``trust_pickle=True`` or ``HUDIFF_TRUST_CKPT=1`` for files you trust (the reference always loads that way,
     antibody_scripts/sample.py:448)."""

@@ -10,7 +10,7 @@ importable and otherwise the built-in slotter (``--numbering``; ``--numbered_fpa
 residues); ``--sample_method inpaint`` grafts with abnumber when importable and otherwise takes pre-grafted chains
 from ``--grafted_fpath`` (everything after the graft -- placement of the identity positions, mask, loc -- is
 hudiff_amd.inputs.antibody_inpaint_row, pinned against the reference's batch_inpaint_input_element);
-``--traditional_method`` (pure abnumber CDR grafting, no model) raises; the similarity
+``--traditional_method`` (pure abnumber CDR grafting, no model: ``traditional_main``) needs abnumber and says so without it; the similarity
 search scores identity over the aligned IMGT slots instead of an abnumber alignment; noise comes from the
 library's counter-based generator keyed by (seed, global row, step), not torch's global mt19937 stream.
 """
@@ -98,6 +98,8 @@ def select_most_similar(parent_tokens, replica_tokens):
 def traditional_main(args):
     """sample.py:539-576: CDR grafting only (abnumber), one 'humanization' row per mouse row and no 'mouse' rows; the log
     directory sits next to the data file."""
+    if D.env_rank_world()[0] != 0:          # no model, nothing to shard: under torchrun only rank 0 grafts and writes
+        return None
     data_sample = "humab" if "humab" in args.data_fpath else ("putative" if "putative" in args.data_fpath else "lab")
     # graft first: without abnumber this raises before any directory is created
     names, human_rows = [], []

@@ -27,15 +27,33 @@ def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def init_process_group(backend: Optional[str] = None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+_active = False      # a process group was formed by init_process_group (also a world-size-1 one, see `force`)
+
+
+def init_process_group(backend: Optional[str] = None, force: Optional[bool] = None):
+    """Initialise torch.distributed from the torchrun environment.  A single process forms no group (the gather is then a
+    local reshape) unless ``force`` / HUDIFF_DIST_FORCE=1 asks for one: a world-size-1 RCCL group is legal and runs the whole
+    collective path -- communicator init with ``device_id``, device tensors, torch's HIP runtime beside the library's own
+    streams -- on a one-GPU box (tests/test_gpu_dist.py)."""
+    global _active
     rank, world, local_rank = env_rank_world()
-    if world == 1:
+    if force is None:
+        force = os.environ.get("HUDIFF_DIST_FORCE") == "1"
+    if world == 1 and not force:
         return None
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
+        _active = True
         return dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     # HUDIFF_DIST_BACKEND=gloo: ranks that share one GPU (tests on a 1-GPU box; RCCL refuses duplicate devices)
     backend = backend or os.environ.get("HUDIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
@@ -43,7 +61,19 @@ def init_process_group(backend: Optional[str] = None):
         dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend)
+    _active = True
     return dist
+
+
+def shutdown():
+    """Destroy the process group init_process_group formed (no-op otherwise)."""
+    global _active
+    if _active:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        _active = False
 
 
 def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int, all_ranks: bool = False) -> Optional[np.ndarray]:
@@ -51,7 +81,7 @@ def gather_rows(local_tokens: np.ndarray, n_rows: int, L: int, all_ranks: bool =
     ``all_ranks`` an all-gather, for host logic that must take the same decision everywhere).
     Blocks may differ by one row; they are padded to the largest block for the collective."""
     rank, world, local_rank = env_rank_world()
-    if world == 1:
+    if world == 1 and not _active:
         return np.asarray(local_tokens, dtype=np.int32).reshape(n_rows, L)
     import torch
     import torch.distributed as dist

@@ -1,4 +1,4 @@
-"""The reference's evaluation sets as pre-slotted integer rows (tests/golden/real_rows.npz, written by
+"""The reference's evaluation sets as pre-slotted integer rows (hudiff_amd/data/real_rows.npz, written by
 scripts/make_real_rows.py from data/antibody_eval_data/HuAb348_data/humanization_pair_data_filter.csv,
 Humab25_data/parental_mouse.csv and data/nanobody_eval_data/abnativ_select_vhh.csv with the built-in IMGT slotter).
 
@@ -16,7 +16,7 @@ import numpy as np
 from . import inputs as I
 from . import tables
 
-_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_rows.npz")
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "real_rows.npz")      # package data: ships with hudiff_amd
 _cache = None
 
 DATASETS = {"huab348": "ab", "humab25": "ab", "vhh": "nb"}
@@ -29,6 +29,9 @@ def available() -> bool:
 def load_rows():
     global _cache
     if _cache is None:
+        if not available():
+            raise FileNotFoundError(f"{_PATH} is missing: the evaluation rows are package data of hudiff_amd "
+                                    "(regenerate with scripts/make_real_rows.py where the reference's CSVs exist)")
         _cache = dict(np.load(_PATH))
     return _cache
 

@@ -4,7 +4,7 @@
 
 The reference's own ``AntiTFNet`` / ``NanoAntiTFNet`` (configs/antibody_train.yml / heavy_train.yml shapes, dropout 0 so that
 the only noise is ``torch.multinomial``'s) run the loop of antibody_scripts/sample.py:499-513 on two real rows (HuAb348 pairs /
-VHH sequences from tests/golden/real_rows.npz) with the recorded Exp(1) noise; inputs, noise, per-step draws and final tokens
+VHH sequences from hudiff_amd/data/real_rows.npz) with the recorded Exp(1) noise; inputs, noise, per-step draws and final tokens
 are stored.  Weights are NOT stored: ``hudiff_amd.synthetic.random_state_dict(kind, cfg, seed)`` (SHA-256 in the fixture).
 The GPU tests replay the noise through the fp32 kernels and -- padded with filler rows to a launch large enough -- through the
 split-precision kernels: both must reproduce the reference's tokens bit for bit.

@@ -6,7 +6,7 @@
 BASELINE.json's configs are quoted on real rows -- HuAb348 ``humanization_pair_data_filter.csv`` (348 mouse pairs),
 Humab25 ``parental_mouse.csv`` (25 pairs), ``abnativ_select_vhh.csv`` (300 VHH) -- which do not exist on the GPU box.
 This script slots every sequence (hudiff_amd.numbering, the same front-end the CLIs use offline) and stores the
-result as small integer arrays in tests/golden/real_rows.npz:
+result as small integer arrays in hudiff_amd/data/real_rows.npz:
 
     huab348_tokens  int8 [348, 291]   slot tokens of VH (152) + VL (139), 21 = empty slot, nothing masked
     huab348_lchain  int8 [348]        light chain type id (1 = lambda, 2 = kappa; utils/tokenizer.py chain ids)
@@ -30,7 +30,7 @@ from hudiff_amd import inputs as I  # noqa: E402
 from hudiff_amd.numbering import number_sequence_builtin  # noqa: E402
 
 REF = "/root/reference/data"
-OUT = os.path.join(ROOT, "tests", "golden", "real_rows.npz")
+OUT = os.path.join(ROOT, "hudiff_amd", "data", "real_rows.npz")
 
 
 def slot_pair(h_seq, l_seq):

@@ -1,5 +1,5 @@
 """BASELINE.json's configurations on the HIP path with the REAL rows of the reference's evaluation sets
-(tests/golden/real_rows.npz = HuAb348 / Humab25 / abnativ_select_vhh slotted by scripts/make_real_rows.py).
+(hudiff_amd/data/real_rows.npz = HuAb348 / Humab25 / abnativ_select_vhh slotted by scripts/make_real_rows.py).
 
 configs[0]  sample.py on Humab25 parental_mouse.csv, --batch_size 1                 -> test_humab25_cli_batch_1
 configs[1]  HuDiff-Ab on HuAb348, 256 rows per GPU                                   -> test_huab348_full_batch

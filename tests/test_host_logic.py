@@ -207,6 +207,47 @@ def test_checkpoint_loader_refuses_foreign_pickles(tmp_path):
     assert ck.load_checkpoint(str(p), trust_pickle=True)["x"] == os.path.join("a", "b")
 
 
+def test_checkpoint_loader_refuses_nested_unpickle_gadgets(tmp_path):
+    """torch.storage._load_from_bytes(b) is torch.load(BytesIO(b), weights_only=False), an unrestricted
+    nested unpickle; torch.serialization.load likewise.  The allow-list is exact (module, name) pairs: neither resolves, and
+    the inner payload never runs."""
+    import io
+    import pickle
+    torch = pytest.importorskip("torch")
+    from hudiff_amd import checkpoint as ck
+    marker = tmp_path / "ran"
+
+    class Inner:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))            # harmless side effect that proves execution
+    inner = io.BytesIO()
+    torch.save(Inner(), inner)
+
+    class ViaLoadFromBytes:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    class ViaSerializationLoad:
+        def __reduce__(self):
+            return (torch.serialization.load, (io.BytesIO(inner.getvalue()),))
+    for n, gadget in enumerate((ViaLoadFromBytes(), ViaSerializationLoad())):
+        p = tmp_path / f"gadget{n}.pt"
+        try:
+            torch.save({"model": {}, "x": gadget}, p)
+        except (TypeError, pickle.PicklingError):        # BytesIO argument not picklable on this torch: the first gadget suffices
+            continue
+        with pytest.raises(RuntimeError, match="allow-list"):
+            ck.load_checkpoint(str(p))
+        assert not marker.exists()
+    # whole modules are never admitted
+    for module, name in (("torch.storage", "_load_from_bytes"), ("torch.serialization", "load"), ("torch._utils", "_rebuild_wrapper_subclass"),
+                         ("builtins", "eval"), ("builtins", "getattr"), ("os", "system"), ("torch", "load"), ("numpy", "load")):
+        assert not ck._allowed(module, name), (module, name)
+    for module, name in (("torch._utils", "_rebuild_tensor_v2"), ("torch", "FloatStorage"), ("torch", "ComplexFloatStorage"),
+                         ("torch", "float32"), ("collections", "OrderedDict"), ("easydict", "EasyDict")):
+        assert ck._allowed(module, name), (module, name)
+
+
 def test_checkpoint_envelopes(tmp_path):
     torch = pytest.importorskip("torch")
     from hudiff_amd import checkpoint as ck
@@ -263,7 +304,7 @@ def test_traditional_method_layout(tmp_path, monkeypatch):
 
 
 def test_evalset_fixture_rows():
-    """tests/golden/real_rows.npz (scripts/make_real_rows.py): the reference's evaluation rows as slot tokens."""
+    """hudiff_amd/data/real_rows.npz (scripts/make_real_rows.py): the reference's evaluation rows as slot tokens."""
     from hudiff_amd import evalsets as E
     z = E.load_rows()
     assert z["huab348_tokens"].shape == (348, 291) and z["humab25_tokens"].shape == (25, 291) and z["vhh_tokens"].shape == (300, 152)
