@@ -163,3 +163,55 @@ def synthetic_batch(kind: str, B: int, seed: int = 2023, mode: str | None = None
         order[r, :len(loc)] = loc
     return dict(tokens=tokens, region=np.repeat(region[None].astype(np.int32), B, 0), chain=chain,
                 order=order, T=np.array(Ts, np.int32), truth=truth, mode=mode)
+
+
+ADVERSARIAL_VARIANTS = ("dc", "massive", "huge", "tiny")
+
+
+def adversarial_state_dict(kind: str, cfg: dict, seed: int, variant: str) -> dict:
+    """``random_state_dict`` bent so that the residual stream takes the statistics trained checkpoints are known for and
+    freshly initialised weights never show (VERDICT r2 "Next" #2) -- the function stays well conditioned (the reference's own
+    float32 result is within ~4e-5 of its float64 evaluation), only the numbers the kernels see get ugly:
+
+    ``dc``       a constant added to every residual-branch output bias of the conv and attention stages: row mean / row std of
+                 the stream reaches ~80 in front of the un-normalised first attention and ~50 in front of the LayerNorms
+                 whose affine part is folded into the next projection (value projections damped so that the offset does
+                 not turn into channel variance)
+    ``massive``  four channels carry |x| ~ 2e4 (out_put biases + 1e4) and two LayerNorm gains are x 30
+    ``huge``     the whole stream scaled by 2^17 (|x| ~ 1e6 > 65504, the fp16 range): embeddings, static branch and every
+                 residual-branch output x 2^17, the un-normalised attention inputs / 2^17
+    ``tiny``     the same with 2^-12 (|x| ~ 2e-3, row std ~ 3e-4 << 2^-3; below the LayerNorm epsilon)
+
+    Used by oracle/make_golden_adversarial.py (loaded into the reference's classes) and by the parity tests."""
+    if variant not in ADVERSARIAL_VARIANTS:
+        raise ValueError(variant)
+    sd = random_state_dict(kind, cfg, seed)
+    rng = np.random.default_rng(seed + 1000)
+    last_w = ("sequence2.2.conv.weight", "out_put.weight", "ff_hl.2.weight")
+    last_b = ("sequence2.2.conv.bias", "out_put.bias", "ff_hl.2.bias")
+    if variant == "dc":
+        for k in sd:
+            if k.endswith(last_b) and ("self_at" in k or "conv_block" in k):
+                sd[k] = (sd[k] + 10.0).astype(np.float32)
+            if k.endswith("value.weight"):
+                sd[k] = (sd[k] * 0.1).astype(np.float32)
+    elif variant == "massive":
+        ch = rng.choice(cfg["sum_d_model"], size=4, replace=False)
+        for k in sd:
+            if "self_at" in k and k.endswith("out_put.bias"):
+                sd[k][ch] += 1.0e4
+            if k.endswith(("norm_hl1.weight", "norm_hl2.weight")):
+                sd[k][ch[:2]] *= 30.0
+    else:
+        s = 2.0 ** (17 if variant == "huge" else -12)
+        static = ("region_encoder.region_layer1.3.weight", "region_encoder.region_layer1.3.bias", "side_encoder.side_mlp.3.weight",
+                  "side_encoder.side_mlp.3.bias", "pos_encoder.pos_lin.ln1.bias", "pos_encoder.pos_lin.ln2.bias")
+        for k in sd:
+            if k.endswith(last_w) or k.endswith(last_b) or k == "aa_encoder.embedder.weight" or k in static:
+                sd[k] = (sd[k] * s).astype(np.float32)
+            if ".attn_hl." in k and k.endswith(("query.weight", "key.weight", "value.weight")):
+                sd[k] = (sd[k] / s).astype(np.float32)
+        # the sinusoid table is a registered buffer of the checkpoint (model/encoder/model.py:70-78): scaled with the rest
+        from .model import _sinusoid_pe
+        sd["pos_encoder.pos_embedding.pe"] = (_sinusoid_pe(cfg["max_len"], cfg["d_model"])[:, None, :] * s).astype(np.float32)
+    return sd

@@ -283,8 +283,22 @@ class OracleNet:
             assert self.L == AB_H_LEN + AB_L_LEN
         self.enc_dil = dilations(int(c["n_encoder_layers"]), int(c["r"]))
         self.conv_dil = dilations(int(c["dual_layers"]), int(c["r"]))
-        self.pe = sinusoid_pe(self.L, int(c["n_pos_model"])).astype(self.dt)
-        self.cos, self.sin = (t.astype(self.dt) for t in rope_table(self.att // self.nhead, self.L))
+        # buffers travel in the state_dict (register_buffer: model/encoder/model.py:70-78 `pe`, cross_attention.py:145-146
+        # `rope`): load_state_dict overwrites the constructor's tables with the checkpoint's, so a state_dict that carries
+        # them wins here too; otherwise they are rebuilt the way the constructor builds them
+        if "pos_encoder.pos_embedding.pe" in sd:
+            self.pe = np.asarray(sd["pos_encoder.pos_embedding.pe"]).reshape(self.L, -1).astype(F32).astype(self.dt)
+        else:
+            self.pe = sinusoid_pe(self.L, int(c["n_pos_model"])).astype(self.dt)
+        self.sd.pop("pos_encoder.pos_embedding.pe", None)
+        ropes = [np.asarray(v) for k, v in sd.items() if k.endswith(".rope")]
+        if ropes:
+            r = ropes[0]
+            r = np.stack([r.real, r.imag], -1) if np.iscomplexobj(r) else r
+            self.cos, self.sin = r[..., 0].astype(F32).astype(self.dt), r[..., 1].astype(F32).astype(self.dt)
+        else:
+            self.cos, self.sin = (t.astype(self.dt) for t in rope_table(self.att // self.nhead, self.L))
+        self.sd = {k: v for k, v in self.sd.items() if not k.endswith(".rope")}
         self.trace: Optional[dict] = None     # set to {} to record intermediate activations
 
     # -- helpers -------------------------------------------------------------------
