@@ -22,7 +22,7 @@ HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_D
 EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",
     "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
-    "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read",
+    "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read", "hd_precision_info",
 ]
 
 
@@ -78,6 +78,7 @@ def load():
     lib.hd_flops_per_row_sample_step.argtypes = [P(HdConfig)]
     lib.hd_flops_per_row_sample_step.restype = C.c_double
     lib.hd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, i32p, P(C.c_int64)]
+    lib.hd_precision_info.argtypes = [vp, i32p, i32p, P(C.c_int64)]
     lib.hd_debug_stop_after.argtypes = [vp, C.c_int32]
     lib.hd_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64]
     _lib = lib

@@ -111,6 +111,11 @@ struct HdModel {
     float* blob = nullptr;
     uint16_t* blobx = nullptr;        // split-precision copies of the GEMM weights (HUDIFF_X3=1 at hd_finalize)
     bool x3 = false;
+    // Range guard of the split-precision kernels: their fp16 (hi, lo) operands are not scaled, so a producer that meets
+    // |x| >= 65504 raises RunState::pad[1]; the forward / sample is then re-run on the fp32 kernels and the model stays on
+    // them (weights whose residual stream leaves the fp16 range do so at every step): x3_suspended, counted in range_fallbacks.
+    bool x3_suspended = false;
+    int64_t range_fallbacks = 0;
     bool attn_x3 = false;                            // HUDIFF_ATTN_X3=1 at hd_finalize: split-precision attention kernel inside the fp32 path
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
@@ -138,6 +143,7 @@ struct HdModel {
         hipGraphExec_t graph_exec = nullptr;
         int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
         int graph_qB = -1, graph_qoff = -1;
+        int graph_x3 = -1;                           // split-precision kernels active when the graph was captured
         const float* graph_qptr = nullptr;           // the injected-noise buffer the captured sample_step_k reads
         // the T-step loop as ONE graph: `loop_steps` child-graph nodes of `graph` in a chain (hd_sample_run)
         hipGraph_t loop_graph = nullptr;
@@ -159,6 +165,8 @@ struct HdModel {
     bool in_session = false;
     int sB = 0, sTmax = 0;
     uint64_t s_row0 = 0;
+    uint64_t s_seed = 0;                             // seed of the last hd_sample_begin / hd_sample_restart (range-guard re-run)
+    int s_steps = 0;                                 // steps enqueued since then (largest t1 of hd_sample_run)
     uint32_t sflags = 0;
     bool s_has_q = false;
     int last_steps = 0; bool timed = false;
@@ -733,7 +741,7 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
 // caller BEFORE it asks the producer for split rows -- x3_use() holds every condition launch_gemm checks again.
 static bool x3_use(const HdModel* m, const Segs& sg, const X3W& x) {
     const long rows = (long)sg.B * sg.L, widest = 3L * m->A > m->D ? 3L * m->A : m->D;       // 32-bit byte offsets in every operand
-    return m->x3 && x.w && rows >= 8192 && rows * widest * 4 < (1L << 31);
+    return m->x3 && !m->x3_suspended && x.w && rows >= 8192 && rows * widest * 4 < (1L << 31);
 }
 static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
@@ -886,7 +894,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         const int seg1 = p.sg.nseg > 1 ? p.sg.base[1] : (int)rows;
         hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p.part, pw, p.N, (int)rows,
                            (const float*)p.C, p.ldc, p.C, p.ldc, (const float2*)nullptr, apply->gamma, apply->beta, apply->k_stride, seg1,
-                           apply->act, apply->split);
+                           apply->act, apply->split, (const RunState*)cur(m).rs);
     }
 }
 
@@ -937,7 +945,7 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
         const bool from_part = x_stats == X_PARTIALS;
         hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
                            ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
-                           w.ln1_g, w.ln1_b, din, seg1, act, 1);
+                           w.ln1_g, w.ln1_b, din, seg1, act, 1, (const RunState*)cur(m).rs);
         GemmP p = base_gemm(m, sg);
         p.A = ws.S1; p.lda = din; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
         p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
@@ -1015,16 +1023,17 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     // ... and address QKV with 32-bit byte offsets
     // HUDIFF_ATTN_X3=1 (read at hd_finalize): the split-precision attention kernel inside the fp32 path as well (fp32 Q|K|V in, fp32 O out); an
     // experiment for the record, off by default: the product path computes in fp32 throughout
-    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
-        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp);
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
-        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp);
+        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     } else if (m->L > 160)
-        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
+        hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0, rsp);
     else
-        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0);
+        hipLaunchKernelGGL(attn_k<10>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0, rsp);
     p = base_gemm(m, sg);
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
@@ -1196,6 +1205,14 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
     return DROP_GEN;
 }
 
+// split-precision kernels (whole path or attention only) currently in use / switched off for good by the range guard
+static bool split_active(const HdModel* m) { return (m->x3 || m->attn_x3) && !m->x3_suspended; }
+static void suspend_split(HdModel* m) {
+    m->x3_suspended = true;
+    m->range_fallbacks += 1;
+    for (auto& ln : m->lane) ln.drop_graphs();      // captured with the split kernels
+}
+
 template <typename T>
 static HdStatus ensure_buf(HdModel* m, T** p, size_t* cap, size_t n) {
     if (n <= *cap) return HD_OK;
@@ -1238,6 +1255,14 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, cur(m).stream));
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
+    if (split_active(m)) {          // range guard: an operand of a split-precision kernel left the fp16 range -> fp32 kernels
+        RunState h{};
+        HIP_TRY(hipMemcpy(&h, cur(m).rs, sizeof(h), hipMemcpyDeviceToHost));
+        if (h.pad[1]) {
+            suspend_split(m);
+            return hd_forward(m, tokens, region, chain, B, flags, seed, row0, step, enc_masks, conv_masks, logits);
+        }
+    }
     return HD_OK;
 }
 
@@ -1265,6 +1290,7 @@ static HdStatus sample_begin_impl(HdModel* m, const int32_t* tokens, const int32
     if (B < 0 || Tmax < 0) return fail(HD_ERR_INVALID, "hd_sample_begin: B = %d, Tmax = %d", B, Tmax);
     HIP_TRY(hipSetDevice(m->device));
     m->sB = B; m->sTmax = Tmax; m->sflags = flags; m->s_has_q = q_noise != nullptr; m->timed = false; m->last_steps = 0;
+    m->s_seed = seed; m->s_steps = 0;
     m->nlanes = 1; m->cl = 0;
     if (B == 0) { m->in_session = true; return HD_OK; }
     HD_TRY(validate_inputs(m, tokens, region, chain, B));
@@ -1360,6 +1386,7 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
 
 extern "C" HdStatus hd_sample_restart(HdModel* m, uint64_t seed) {
     if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_restart: no open session");
+    m->s_seed = seed; m->s_steps = 0;
     if (m->sB == 0) return HD_OK;
     HIP_TRY(hipSetDevice(m->device));
     for (int l = 0; l < m->nlanes; ++l) {
@@ -1377,6 +1404,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
     if (t0 < 0 || t1 < t0 || t1 > m->sTmax) return fail(HD_ERR_INVALID, "hd_sample_run: steps [%d,%d) outside [0,%d]", t0, t1, m->sTmax);
     if (m->sB == 0 || t1 == t0) return HD_OK;
     HIP_TRY(hipSetDevice(m->device));
+    if (t1 > m->s_steps) m->s_steps = t1;
     const int dm = drop_mode_of(m, m->sflags);
     const bool use_graph = !(m->sflags & HD_NO_GRAPH) && dm != DROP_INJECT;
     for (int l = 0; l < m->nlanes; ++l) {
@@ -1388,7 +1416,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
         const uint32_t gflags = m->sflags & HD_NO_PRUNE;
         if (!ln.graph_exec || ln.graph_B != ln.B || ln.graph_flags != gflags || ln.graph_drop != dm || ln.graph_q != m->s_has_q ||
             ln.graph_Tmax != m->sTmax || ln.graph_qB != m->sB || ln.graph_qoff != ln.row_off ||
-            ln.graph_qptr != (m->s_has_q ? m->qnoise : nullptr)) {
+            ln.graph_qptr != (m->s_has_q ? m->qnoise : nullptr) || ln.graph_x3 != (split_active(m) ? 1 : 0)) {
             ln.drop_graphs();
             HIP_TRY(hipStreamSynchronize(ln.stream));
             HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
@@ -1399,6 +1427,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
             HIP_TRY(hipGraphInstantiate(&ln.graph_exec, ln.graph, nullptr, nullptr, 0));
             ln.graph_B = ln.B; ln.graph_flags = gflags; ln.graph_drop = dm; ln.graph_q = m->s_has_q; ln.graph_Tmax = m->sTmax;
             ln.graph_qB = m->sB; ln.graph_qoff = ln.row_off; ln.graph_qptr = m->s_has_q ? m->qnoise : nullptr;
+            ln.graph_x3 = split_active(m) ? 1 : 0;
         }
     }
     for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipEventRecord(m->lane[l].ev0, m->lane[l].stream));
@@ -1455,25 +1484,53 @@ extern "C" HdStatus hd_sync(HdModel* m) {
     return HD_OK;
 }
 
-extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
-    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_end: no open session");
-    m->in_session = false;
-    if (m->sB == 0) return HD_OK;
-    if (!tokens) return fail(HD_ERR_INVALID, "hd_sample_end: null tokens");
-    HIP_TRY(hipSetDevice(m->device));
+static HdStatus sample_collect(HdModel* m, int32_t* tokens, bool* numeric, bool* range) {
     for (int l = 0; l < m->nlanes; ++l) {
         HdModel::Lane& ln = m->lane[l];
         HIP_TRY(hipMemcpyAsync(tokens + (size_t)ln.row_off * m->L, ln.ws.tokens, (size_t)ln.B * m->L * sizeof(int32_t), hipMemcpyDeviceToHost, ln.stream));
     }
     for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
-    m->cl = 0;
+    *numeric = *range = false;
     for (int l = 0; l < m->nlanes; ++l) {
         RunState h{};
         HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
-        if (h.pad[0])
-            return fail(HD_ERR_NUMERIC, "hd_sample: non-finite logits (NaN / inf) at some denoiser step -- weights or inputs out of range; "
-                                        "the reference's torch.multinomial raises at this point");
+        if (h.pad[0]) *numeric = true;
+        if (h.pad[1]) *range = true;
     }
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
+    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_end: no open session");
+    if (m->sB == 0) { m->in_session = false; return HD_OK; }
+    if (!tokens) { m->in_session = false; return fail(HD_ERR_INVALID, "hd_sample_end: null tokens"); }
+    HIP_TRY(hipSetDevice(m->device));
+    bool numeric = false, range = false;
+    HdStatus s = sample_collect(m, tokens, &numeric, &range);
+    if (s == HD_OK && range && split_active(m)) {
+        // range guard (see HdModel::x3_suspended): some operand of a split-precision kernel left the fp16 range during this
+        // sample.  The whole sample is repeated on the fp32 kernels -- same resident inputs, same noise key, same steps --
+        // and the model stays on them.
+        suspend_split(m);
+        const int steps = m->s_steps;
+        s = hd_sample_restart(m, m->s_seed);
+        if (s == HD_OK && steps > 0) s = hd_sample_run(m, 0, steps);
+        if (s == HD_OK) s = sample_collect(m, tokens, &numeric, &range);
+    }
+    m->in_session = false;
+    m->cl = 0;
+    if (s != HD_OK) return s;
+    if (numeric)
+        return fail(HD_ERR_NUMERIC, "hd_sample: non-finite logits (NaN / inf) at some denoiser step -- weights or inputs out of range; "
+                                    "the reference's torch.multinomial raises at this point");
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_precision_info(HdModel* m, int32_t* split_built, int32_t* split_in_use, int64_t* range_fallbacks) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_precision_info: null model");
+    if (split_built) *split_built = (m->x3 ? 1 : 0) | (m->attn_x3 ? 2 : 0);
+    if (split_in_use) *split_in_use = split_active(m) ? 1 : 0;
+    if (range_fallbacks) *range_fallbacks = m->range_fallbacks;
     return HD_OK;
 }
 

@@ -54,7 +54,19 @@ struct RunState {
     uint32_t seed_lo, seed_hi;
     uint32_t row0;
     uint32_t pad[4];       // pad[0]: set by sample_step_k when a visited row had non-finite logits
+                           // pad[1]: range guard of the split-precision kernels -- set by whoever writes an fp16 (hi, lo) split of
+                           //         a value with |x| >= X16_LIMIT (hi would round to inf); the host re-runs on the fp32 kernels
 };
+// fp16 holds |x| < 65520 before rounding to infinity; operands of the split-precision kernels are not scaled (see gemm_x3_k),
+// so every producer of a split checks its values against this and raises RunState::pad[1] (two v_max3_f32 per float4)
+constexpr float X16_LIMIT = 65504.0f;
+__device__ __forceinline__ float absmax4(float m, const float __attribute__((ext_vector_type(4))) v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void raise_range_flag(const RunState* rs, float vmax) {
+    // NaN compares false: a NaN operand is not a range problem (it surfaces as HD_ERR_NUMERIC / in the logits either way)
+    if (vmax >= X16_LIMIT) atomicOr(const_cast<uint32_t*>(&rs->pad[1]), 1u);
+}
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -286,6 +298,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int wrow0 = m0 + wm * WTM;                  // first tile row of this wave within the segment (uniform)
     const int nv = min(WTN, N - (n0 + wn * WTN));     // valid columns of this wave's slice (uniform)
     const float inv_nv = 1.0f / (float)max(nv, 1);
+    float vmax = 0.f;                                 // largest |value| this lane wrote in split form (range guard)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // residual values of this pass are requested up front (each lane reads exactly the elements it will
@@ -365,6 +378,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 h16x4 hh, ll;
                 split4(v, hh, ll);
+                if (valid) vmax = absmax4(vmax, v);
                 float* base = c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
                 const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
@@ -395,6 +409,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         }
         __builtin_amdgcn_wave_barrier();              // reads done before the next pass overwrites the slice
     }
+    if (((F & EPI_CSPLIT) || (F & EPI_C2)) && (c_split || has_c2)) raise_range_flag(p.rs, vmax);
     if (has_part) {
         // slice-major [slice][row]: the wave's WTM row partials go out as one contiguous run
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -993,7 +1008,7 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                                                    const float* X, int ldx, float* Y, int ldy, const float2* __restrict__ stats,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, int k_stride, int seg1_row0,
-                                                   int act, int split_out) {
+                                                   int act, int split_out, const RunState* __restrict__ rs) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     // the row itself is requested before the statistics are merged (the pass is bound by load round trips, not bandwidth:
@@ -1022,6 +1037,7 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
     float* y = Y + (long)row * ldy;
     if (split_out) {                                   // C <= 1024
         _Float16* yh = reinterpret_cast<_Float16*>(y);
+        float vmax = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -1032,10 +1048,12 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                 for (int k = 0; k < 4; ++k) w[k] = act_f((v[j][k] - mean) * rstd * gv[k] + bv[k], act);
                 f16x4 hh, ll;
                 split4(w, hh, ll);
+                vmax = absmax4(vmax, w);
                 *reinterpret_cast<f16x4*>(yh + c) = hh;
                 *reinterpret_cast<f16x4*>(yh + C + c) = ll;
             }
         }
+        raise_range_flag(rs, vmax);
         return;
     }
     for (int c = lane * 4; c < C; c += 256) {
@@ -1232,9 +1250,11 @@ template <int NKT, int ABL = 0>
 __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const float* __restrict__ QKV, int ldq, int att,
                                                           const float* __restrict__ rope_cos,
                                                           const float* __restrict__ rope_sin,
-                                                          float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
+                                                          float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split,
+                                                          const RunState* __restrict__ rs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VS = att_vs(NKT);
+    float vmax = 0.f;                                  // range guard of the split output (o_split)
     const int L = sg.L;
     float* Ks = smem;
     float* Vs = smem + (size_t)L * ATT_KS;
@@ -1407,6 +1427,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                 if (o_split) {                         // split rows for the out-projection's gemm_x3_k (ldo halfs hi, then lo)
                     f16x4 hh, ll;
                     split4(o, hh, ll);
+                    vmax = absmax4(vmax, o);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
                     *reinterpret_cast<f16x4*>(orow + col) = hh;
                     *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
@@ -1416,6 +1437,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
             }
         }
     }
+    if (o_split) raise_range_flag(rs, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1451,7 +1473,8 @@ template <int KT>
 __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
                                                             const float* __restrict__ rope_cos,
                                                             const float* __restrict__ rope_sin,
-                                                            float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split) {
+                                                            float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split,
+                                                            const RunState* __restrict__ rs) {
     typedef AxGeom<KT> G;
     constexpr int AX_KT = KT, AX_KROWS = G::KROWS, AX_VKEYS = G::VKEYS, AX_KPLANE = G::KPLANE, AX_VPLANE = G::VPLANE;
     // KT <= 10 (EXACT): the K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the
@@ -1485,6 +1508,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
     //      lane = d: 8 row loads of 256 B each, two 16-byte writes).  Every global load of both is issued before the first
     //      value is consumed: one exposed round trip per block instead of two.
     {
+        float vmax = 0.f;                              // range guard: K and V are split from fp32 values here (X16_LIMIT)
         constexpr int NST = (AX_KROWS * 16 + ATT_THREADS - 1) / ATT_THREADS;
         constexpr int NCHUNK = AX_VKEYS / 8;                          // 40 / 20 chunks of 8 keys
         constexpr int NCH = (NCHUNK + ATT_THREADS / 64 - 1) / (ATT_THREADS / 64);
@@ -1525,6 +1549,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
                 f16x4 hh, ll;
                 split4(kr, hh, ll);
+                vmax = absmax4(vmax, kr);
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
                 *reinterpret_cast<f16x4*>(Kh + off) = hh;
                 *reinterpret_cast<f16x4*>(Kl + off) = ll;
@@ -1547,6 +1572,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 }
                 f16x4 h4, l4;
                 split4(x4, h4, l4);
+                vmax = absmax4(vmax, x4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { hh[4 * q4 + e] = h4[e]; ll[4 * q4 + e] = l4[e]; }
             }
@@ -1554,6 +1580,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
             *reinterpret_cast<f16x8*>(Vh + off) = hh;
             *reinterpret_cast<f16x8*>(Vl + off) = ll;
         }
+        raise_range_flag(rs, vmax);    // (O is a convex combination of the V rows: covered by the check on V)
     }
     __syncthreads();
 
@@ -1577,6 +1604,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         const long qrow = sg.row(b, qc);
         // Q fragment (B operand): lane holds Q[q][32 ks + 8 g + 0..7], rotated, pre-scaled by log2(e) / 8, split
         f16x8 qh[2], ql[2];
+        float vmax = 0.f;                              // range guard of this tile's Q split
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -1591,10 +1619,12 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 r[2] = (v[2] * cs.y - v[3] * sn.y) * QS; r[3] = (v[2] * sn.y + v[3] * cs.y) * QS;
                 f16x4 hh, ll;
                 split4(r, hh, ll);
+                vmax = absmax4(vmax, r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { qh[ks][4 * hf + e] = hh[e]; ql[ks][4 * hf + e] = ll[e]; }
             }
         }
+        raise_range_flag(rs, vmax);
         // S^T tiles (keys x queries), two key tiles per pass: two independent accumulator chains
         f32x4 st[AX_KT + 1];
 #pragma unroll

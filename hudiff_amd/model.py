@@ -246,6 +246,14 @@ class _Denoiser:
         L.check(self._lib.hd_last_run_ms(self._h, C.byref(ms), C.byref(steps)))
         return float(ms.value), int(steps.value)
 
+    def precision_info(self):
+        """{'split_built', 'split_in_use', 'range_fallbacks'} (hd_precision_info): whether this handle carries the split-precision
+        kernels (HUDIFF_X3 / HUDIFF_ATTN_X3 at load time), whether they are still in use, and how many calls were repeated on
+        the fp32 kernels because an operand left the fp16 range."""
+        built, use, n = C.c_int32(), C.c_int32(), C.c_int64()
+        L.check(self._lib.hd_precision_info(self._h, C.byref(built), C.byref(use), C.byref(n)))
+        return {"split_built": int(built.value), "split_in_use": bool(use.value), "range_fallbacks": int(n.value)}
+
     def debug_stop_after(self, stage):
         L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
 

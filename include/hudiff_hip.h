@@ -163,6 +163,16 @@ double hd_flops_per_row_forward(const HdConfig* cfg);
 /* FLOPs one hd_sample step actually executes per row (last attention block pruned to the visited row, its value side
  * taken through the input rows instead of a V projection of every row). */
 double hd_flops_per_row_sample_step(const HdConfig* cfg);
+/* Precision route of this handle.  The product path multiplies in fp32 on the matrix cores.  With HUDIFF_X3=1 (or
+ * HUDIFF_ATTN_X3=1) in the environment of hd_finalize, launches of >= 8192 activation rows run "split-precision" kernels
+ * instead: every fp32 operand is hi + lo with hi = fp16(x), lo = fp16(x - hi) and a product is three fp16 MFMAs with fp32
+ * accumulation (as close to the exact dot product as the fp32 kernels).  Operands are not scaled, so the route is valid for
+ * |x| < 65504 only: every producer of a split checks its values, and when one is out of range the forward / sample is
+ * repeated on the fp32 kernels inside the same call (same inputs, same noise) and the handle stays on them.
+ *   split_built   bit 0: split-precision weight images were built, bit 1: split-precision attention inside the fp32 path
+ *   split_in_use  1 while eligible launches take the split-precision kernels, 0 after the range guard switched them off
+ *   range_fallbacks  number of calls that were repeated on the fp32 kernels                                            */
+HdStatus hd_precision_info(HdModel* m, int32_t* split_built, int32_t* split_in_use, int64_t* range_fallbacks);
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -60,6 +60,14 @@ def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
         fill, tokens, region, chain = _big_batch(kind, z, B)
         logits = m(tokens, region, chain, dropout="off")
         assert np.isfinite(logits).all()
+        info = m.precision_info()
+        if path == "x3":
+            # |x| ~ 1e6 cannot be written as fp16 (hi, lo): the range guard must have repeated the forward on the fp32 kernels
+            # (and only there: the other variants stay on the split-precision kernels)
+            assert info["split_built"] & 1
+            assert info["range_fallbacks"] == (1 if variant == "huge" else 0) and info["split_in_use"] == (variant != "huge")
+        else:
+            assert info == {"split_built": 0, "split_in_use": False, "range_fallbacks": 0}
         e32 = float(np.abs(logits[:2] - z["logits"]).max())
         e64 = float(np.abs(logits[:2] - z["logits_f64"]).max())
         assert e32 < LOGIT_TOL and e64 < LOGIT_TOL, (kind, variant, path, e32, e64, float(z["reference_f32_vs_f64"]))
@@ -79,3 +87,34 @@ def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
             assert np.array_equal(out[:2], z["final"]), (kind, variant, path, lanes)
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_range_guard_inside_a_sampling_session(hip, kind):
+    """The guard trips in the middle of hd_sample (graph replays, two lanes): hd_sample_end repeats the whole sample on the fp32
+    kernels with the same noise, so the tokens equal those of a handle that never had the split-precision kernels."""
+    z, cfg, sd = load_adv(kind, "huge")
+    cfg = dict(cfg, dropout=0.5 if kind == "nb" else 0.2)          # generated dropout: must be re-drawn identically in the re-run
+    mx, m32 = _model(hip, kind, cfg, sd, x3=True), _model(hip, kind, cfg, sd, x3=False)
+    try:
+        B = 72 if kind == "ab" else 120                              # two lanes, each >= 8192 activation rows
+        fill, tokens, region, chain = _big_batch(kind, z, B)
+        T = np.minimum(fill["T"], 5)
+        args = (tokens, region, chain, fill["order"], T)
+        got = mx.sample(*args, seed=21, row0=7)
+        assert mx.precision_info() == {"split_built": 1, "split_in_use": False, "range_fallbacks": 1}
+        want = m32.sample(*args, seed=21, row0=7)
+        assert np.array_equal(got, want)
+        again = mx.sample(*args, seed=21, row0=7)                    # stays on the fp32 kernels: no second fallback
+        assert np.array_equal(again, want) and mx.precision_info()["range_fallbacks"] == 1
+        # split session API (bench.py's shape): begin / restart / run in pieces / end
+        mx2 = _model(hip, kind, cfg, sd, x3=True)
+        try:
+            mx2.sample_begin(*args, seed=1, row0=7)
+            mx2.sample_restart(21)
+            mx2.sample_run(0, 2); mx2.sample_run(2, 5)
+            assert np.array_equal(mx2.sample_end(), want) and mx2.precision_info()["range_fallbacks"] == 1
+        finally:
+            mx2.close()
+    finally:
+        mx.close(); m32.close()
