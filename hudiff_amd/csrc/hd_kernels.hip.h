@@ -60,6 +60,9 @@ struct RunState {
 // fp16 holds |x| < 65520 before rounding to infinity; operands of the split-precision kernels are not scaled (see gemm_x3_k),
 // so every producer of a split checks its values against this and raises RunState::pad[1] (two v_max3_f32 per float4)
 constexpr float X16_LIMIT = 65504.0f;
+#ifndef HD_GUARD_MASK
+#define HD_GUARD_MASK 31     // bisecting aid: 1 GEMM epilogue, 2 ln_apply_k, 4 attn_k, 8 attn_x3_k staging, 16 attn_x3_k Q
+#endif
 __device__ __forceinline__ float absmax4(float m, const float __attribute__((ext_vector_type(4))) v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
@@ -223,19 +226,41 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // last LDS read).
 // (hi, lo) fp16 split of four fp32 values, hi = fp16(x), lo = fp16(x - hi): two packed conversions for the high parts and one
 // v_fma_mix{lo,hi}_f16 per low part (fp16 operand hi, fp32 operand x, fp16 result: x - hi is exact in fp32, so the single
-// rounding is the one the conversion would commit) -- 6 instructions where convert / convert back / subtract / convert takes 14;
-// bit-identical on 16 M random bit patterns incl. fp16 subnormals (checked on the device when this was introduced).
+// rounding is the one the conversion would commit) -- 6 instructions where convert / convert back / subtract / convert takes 14
+// (10 as hipcc compiles the plain C form); bit-identical on 16 M random bit patterns incl. fp16 subnormals.
+//
+// The four v_fma_mix are ONE asm statement that carries its own wait states.  hipcc does not model the instructions inside an
+// asm string, so it pads none of their hazards (guide section 5.7): a VGPR written by the string and then read as an MFMA
+// operand needs 2 wait states, a half-register write (op_sel destination) 1 before any VALU reader.  Round 2's version issued
+// four separate statements with no padding; it happened to work until an unrelated edit (the range guard in attn_x3_k) let the
+// scheduler place an MFMA one instruction behind the last v_fma_mixhi: every row of HuDiff-Ab came out 2e-2 wrong, silently
+// (found by bisecting with -DHD_SPLIT4_MODE, round 3).  Now: the two registers interleaved (lo, lo, hi, hi), early-clobber
+// outputs, `s_nop 1` closing the string.  Inputs must not come straight from a transcendental instruction (v_exp / v_rcp: one
+// wait state hipcc would not insert either); no caller does that.
+// HD_SPLIT4_MODE=1 builds the compiler-visible form instead (A/B aid).
+#ifndef HD_SPLIT4_MODE
+#define HD_SPLIT4_MODE 0
+#endif
 typedef _Float16 hd_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     hh = __builtin_convertvector(v, hd_f16x4);
+#if HD_SPLIT4_MODE == 1
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ll[c] = (_Float16)__builtin_fmaf((float)hh[c], -1.0f, v[c]);
+#else
     const u32x2_t h = __builtin_bit_cast(u32x2_t, hh);
-    u32x2_t l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[0]) : "v"(h[0]), "v"(v[0]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[0]) : "v"(h[0]), "v"(v[1]));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[1]) : "v"(h[1]), "v"(v[2]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[1]) : "v"(h[1]), "v"(v[3]));
+    unsigned int l0, l1;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1)
+        : "v"(h[0]), "v"(h[1]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    const u32x2_t l = {l0, l1};
     ll = __builtin_bit_cast(hd_f16x4, l);
+#endif
 }
 
 // F: the epilogue features that MAY be present (each is still tested at run time); a caller that knows a launch uses only a few
@@ -378,7 +403,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 h16x4 hh, ll;
                 split4(v, hh, ll);
-                if (valid) vmax = absmax4(vmax, v);
+                if ((HD_GUARD_MASK & 1) && valid) vmax = absmax4(vmax, v);
                 float* base = c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
                 const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
@@ -1048,7 +1073,7 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                 for (int k = 0; k < 4; ++k) w[k] = act_f((v[j][k] - mean) * rstd * gv[k] + bv[k], act);
                 f16x4 hh, ll;
                 split4(w, hh, ll);
-                vmax = absmax4(vmax, w);
+                if (HD_GUARD_MASK & 2) vmax = absmax4(vmax, w);
                 *reinterpret_cast<f16x4*>(yh + c) = hh;
                 *reinterpret_cast<f16x4*>(yh + C + c) = ll;
             }
@@ -1427,7 +1452,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                 if (o_split) {                         // split rows for the out-projection's gemm_x3_k (ldo halfs hi, then lo)
                     f16x4 hh, ll;
                     split4(o, hh, ll);
-                    vmax = absmax4(vmax, o);
+                    if (HD_GUARD_MASK & 4) vmax = absmax4(vmax, o);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
                     *reinterpret_cast<f16x4*>(orow + col) = hh;
                     *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
@@ -1549,7 +1574,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
                 f16x4 hh, ll;
                 split4(kr, hh, ll);
-                vmax = absmax4(vmax, kr);
+                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, kr);
                 const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
                 *reinterpret_cast<f16x4*>(Kh + off) = hh;
                 *reinterpret_cast<f16x4*>(Kl + off) = ll;
@@ -1572,7 +1597,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 }
                 f16x4 h4, l4;
                 split4(x4, h4, l4);
-                vmax = absmax4(vmax, x4);
+                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, x4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { hh[4 * q4 + e] = h4[e]; ll[4 * q4 + e] = l4[e]; }
             }
@@ -1619,7 +1644,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
                 r[2] = (v[2] * cs.y - v[3] * sn.y) * QS; r[3] = (v[2] * sn.y + v[3] * cs.y) * QS;
                 f16x4 hh, ll;
                 split4(r, hh, ll);
-                vmax = absmax4(vmax, r);
+                if (HD_GUARD_MASK & 16) vmax = absmax4(vmax, r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { qh[ks][4 * hf + e] = hh[e]; ql[ks][4 * hf + e] = ll[e]; }
             }
