@@ -672,12 +672,14 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         hipLaunchKernelGGL(side_vec_k, dim3(c.n_side), dim3(256), 0, cur(m).stream, m->sidew, se, d, m->side_vec);
         HIP_TRY(hipGetLastError());
     }
-    const size_t smem = (size_t)L * (ATT_KS + att_vs(L > 160 ? 19 : 10)) * sizeof(float);
+    // upper limits of the dynamic LDS requests (the launches ask for lds_safe_request(...) <= these)
+    const int att_cap = LDS_PER_CU;
     // (a split-precision model still runs the fp32 attention kernel for launches too small for the split kernels)
-    if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<19>::SMEM));
-    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AxGeom<10>::SMEM));
+    if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    static_assert(lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS) <= LDS_PER_CU && lds_safe_request(AxGeom<10>::SMEM, ATT_THREADS) <= LDS_PER_CU, "LDS co-residency rule");
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
     m->finalized = true;
@@ -1015,7 +1017,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
     if (x3) { p.A = x_split; use_x3(p, w.wqkvx); }
     launch_gemm(m, p, false, false);
-    const size_t smem = (size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float);
+    // dynamic LDS requests obey the co-residency rule (hd_kernels.hip.h): a request whose co-resident blocks would fill the
+    // CU's 160 KB is padded until one block fewer fits
+    const size_t smem = (size_t)lds_safe_request((int)((size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float)), ATT_THREADS);
     dim3 grid(sg.B * m->cfg.nhead);
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
@@ -1027,9 +1031,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
-        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)AxGeom<19>::SMEM, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
-        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
+        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)lds_safe_request(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     } else if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0, rsp);
     else
@@ -1094,7 +1098,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
                        at_part, at_pw, at_rows, D);
     if (via_rows) {
         hipLaunchKernelGGL(row_value_k, dim3(B, (D + 255) / 256), dim3(256), 0, st, ws.AT, D, ws.PW, ws.YV, m->cfg.nhead, sg);
-        hipLaunchKernelGGL(head_proj_k, dim3((B + 3) / 4, m->cfg.nhead), dim3(256), (size_t)4 * D * sizeof(float), st, ws.YV, D,
+        hipLaunchKernelGGL(head_proj_k, dim3((B + 3) / 4, m->cfg.nhead), dim3(256), (size_t)lds_safe_request(4 * D * (int)sizeof(float), 256), st, ws.YV, D,
                            w.a2.wqkv + 2 * A, 3 * A, w.a2.bqkv + 2 * A, ws.Oc, A, m->cfg.nhead, B);
     }
     // at_c = at_c + o Wo + bo

@@ -72,6 +72,26 @@ __device__ __forceinline__ void raise_range_flag(const RunState* rs, float vmax)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS co-residency rule.  A CU has 160 KB of LDS.  Round 2 met workgroups of ONE kernel that together filled it exactly
+// (2 x 81 920 B) and then produced wrong rows now and then; 2 KB of slack cured it and the cause was never pinned down (DESIGN.md
+// section 9).  The rule since: the blocks of a kernel that can be co-resident on a CU never sum to more than 160 KB - 2 KB.
+//   n = min(160 KB / bytes, 32 waves / waves per block)  blocks fit; n * bytes <= LDS_CORESIDENT_MAX must hold.
+// Kernels with static LDS assert it at compile time (lds_fill_ok); launches with dynamic LDS ask for lds_safe_request(bytes),
+// which pads a request that would fill the CU until one block fewer fits (hd_api.hip).
+// ------------------------------------------------------------------------------------------------
+constexpr int LDS_PER_CU = 160 * 1024, LDS_CORESIDENT_MAX = LDS_PER_CU - 2048, WAVES_PER_CU = 32;
+__host__ __device__ constexpr int lds_blocks_per_cu(int bytes, int threads) {
+    const int by_lds = bytes > 0 ? LDS_PER_CU / bytes : WAVES_PER_CU, by_waves = WAVES_PER_CU / ((threads + 63) / 64);
+    return by_lds < by_waves ? by_lds : by_waves;
+}
+__host__ __device__ constexpr bool lds_fill_ok(int bytes, int threads) {
+    return (long)lds_blocks_per_cu(bytes, threads) * bytes <= LDS_CORESIDENT_MAX;
+}
+__host__ __device__ constexpr int lds_safe_request(int bytes, int threads) {
+    // smallest request >= bytes that obeys the rule: if n blocks would overfill, ask for just too much for n blocks
+    return lds_fill_ok(bytes, threads) ? bytes : LDS_PER_CU / lds_blocks_per_cu(bytes, threads) + 64;
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -500,6 +520,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
     static_assert((BN * KQ) % 256 == 0, "every thread stages W");
     static_assert((BK * LDA) % 4 == 0, "Bs must stay 16-byte aligned");
 
+    static_assert(lds_fill_ok(SM_FLOATS * 4, 256), "co-resident blocks of this kernel would fill the CU's LDS (see LDS co-residency rule)");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float (*As)[LDA] = reinterpret_cast<float (*)[LDA]>(smem);
     float (*Bs)[LDB] = reinterpret_cast<float (*)[LDB]>(smem + BK * LDA);
@@ -840,6 +861,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
     static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0, "tile / wave split");
+    static_assert(lds_fill_ok(SM_FLOATS * 4, NT), "co-resident blocks of this kernel would fill the CU's LDS (see LDS co-residency rule)");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A hi, A lo, W hi, W lo
 
@@ -1783,6 +1805,7 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
                                                    const int32_t* __restrict__ T, int Tmax,
                                                    const RunState* __restrict__ rs, Segs sg, float* __restrict__ Pw,
                                                    const float2* __restrict__ spart, int spw, long spart_rows, int Kc) {
+    static_assert(lds_fill_ok((4 * ATT_HD + 4 * 320) * 4, 256), "LDS co-residency rule");
     __shared__ float qs[4][ATT_HD];
     __shared__ float ps[4][320];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1879,6 +1902,7 @@ constexpr int RV_MAX_HEADS = 8;
 // loads are in flight per thread (the kernel is bound by reading X once: L D floats per sequence)
 __global__ void __launch_bounds__(256) row_value_k(const float* __restrict__ X, int D, const float* __restrict__ Pw,
                                                     float* __restrict__ Y, int nhead, Segs sg) {
+    static_assert(lds_fill_ok(320 * RV_MAX_HEADS * 4, 256), "LDS co-residency rule");
     __shared__ float ps[320][RV_MAX_HEADS];
     const int b = blockIdx.x, L = sg.L, tid = threadIdx.x;
     for (int i = tid; i < RV_MAX_HEADS * 320; i += 256) {

@@ -44,9 +44,10 @@ def _pair(hip, kind, seed):
 
 @pytest.mark.parametrize("kind", ["ab", "nb"])
 def test_x3_logits_vs_float64_oracle(hip, kind):
-    """Production width, real rows, launches big enough for the 128 x 128 kernels.  Dropout on is the hard case: with
-    random weights the x2 rescaling of 12 dropout sites drives the raw residual stream past fp16's range -- the per-row
-    power-of-two scaling of gemm_x3_k is what keeps the split exact there."""
+    """Production width, real rows, launches big enough for the 128 x 128 kernels.  Dropout on is the hard case: the x2
+    rescaling at 12 dropout sites inflates the raw residual stream (|x| of several thousand with these weights).  Activations
+    are NOT scaled before the fp16 (hi, lo) split (hd_kernels.hip.h, gemm_x3_k): the split is exact to 2^-22 relative for
+    |x| < 65504, and beyond that the range guard repeats the call on the fp32 kernels (tests/test_gpu_adversarial.py)."""
     from hudiff_amd import evalsets as E
     cfg, sd, m32, mx3 = _pair(hip, kind, seed=0)
     try:
@@ -205,3 +206,54 @@ def test_split_attention_kernel_inside_the_fp32_path(hip, kind):
         assert np.array_equal(m32.sample(*args, seed=11, row0=0), mat.sample(*args, seed=11, row0=0))
     finally:
         m32.close(); mat.close()
+
+
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_x3_stress_200_forwards_two_lanes(hip, kind):
+    """VERDICT r2 "Next" #3 (ii): the co-residency findings of round 2 were never root-caused, so they are excluded structurally
+    (LDS co-residency rule, hd_kernels.hip.h) and watched for: >= 200 denoiser forwards per model on the split-precision kernels,
+    two lanes drifting against each other on two streams (graph replays; both lanes' kernels co-resident on the CUs), generated
+    dropout on -- every repeat must give bit-identical tokens, and repeated hd_forward calls bit-identical logits."""
+    from hudiff_amd import evalsets as E
+    cfg, sd, m32, mx3 = _pair(hip, kind, seed=0)
+    try:
+        B = 128 if kind == "ab" else 160                 # two lanes of >= 8192 activation rows each
+        batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
+        T = np.minimum(batch["T"], 6)
+        args = (batch["tokens"], batch["region"], batch["chain"], batch["order"], T)
+        first = mx3.sample(*args, seed=31, row0=0)
+        assert np.array_equal(first, m32.sample(*args, seed=31, row0=0))
+        n_forwards = 2 * 6
+        for rep in range(17):                            # 18 samples x 6 steps x 2 lanes = 216 forwards
+            assert np.array_equal(mx3.sample(*args, seed=31, row0=0), first), rep
+            n_forwards += 2 * 6
+        assert n_forwards >= 200
+        kw = dict(dropout="faithful", seed=9, row0=0, step=1)
+        lg = mx3(batch["tokens"][:64], batch["region"][:64], None if batch["chain"] is None else
+                 np.concatenate([batch["chain"][:64], batch["chain"][B:B + 64]]), **kw) if kind == "ab" else \
+            mx3(batch["tokens"], batch["region"], None, **kw)
+        for _ in range(12):
+            again = mx3(batch["tokens"][:64], batch["region"][:64], np.concatenate([batch["chain"][:64], batch["chain"][B:B + 64]]), **kw) \
+                if kind == "ab" else mx3(batch["tokens"], batch["region"], None, **kw)
+            assert np.array_equal(again, lg)
+        assert mx3.precision_info() == {"split_built": 1, "split_in_use": True, "range_fallbacks": 0}
+    finally:
+        m32.close(); mx3.close()
+
+
+def test_whole_gpu_suite_with_split_precision_as_process_default(tmp_path):
+    """VERDICT r2 "Next" #3 (iii): every -m gpu test once more in a process that has HUDIFF_X3=1 exported, i.e. with the
+    split-precision kernels as the default of every handle the suite builds (reference traces, adversarial vectors, CLIs,
+    sharding, ...).  Tests that pin the default-off behaviour skip themselves there."""
+    import subprocess
+    import sys
+    if os.environ.get("HUDIFF_X3", "0") not in ("", "0"):
+        pytest.skip("already inside the HUDIFF_X3=1 run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HUDIFF_X3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "--deselect", "tests/test_gpu_x3.py::test_whole_gpu_suite_with_split_precision_as_process_default"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail + r.stderr[-1500:]
+    assert " passed" in tail and " failed" not in tail, tail
