@@ -52,13 +52,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the 'best batch' CPU leg (B = 1 is always timed too)")
     ap.add_argument("--cpu-steps", type=int, default=16)
-    ap.add_argument("--traffic", choices=["auto", "live", "file", "off"], default="auto",
-                    help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a 4-step run of "
-                         "this script in a subprocess after the timed region; file = profiles/r02/pmc_traffic.json")
+    ap.add_argument("--pmc", "--traffic", dest="pmc", choices=["auto", "live", "off"], default="auto",
+                    help="roofline.traffic / hbm_gbps / mfma_busy: live = two rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE + "
+                         "SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE) over a 4-step run of this script in a subprocess after the timed region")
     ap.add_argument("--cpu-impl", choices=["auto", "torch", "numpy"], default="auto",
                     help="CPU baseline on the oracle's PyTorch-CPU variant (auto: when torch is importable) or on numpy")
     ap.add_argument("--no-split-line", action="store_true",
                     help="skip the extra `split_precision` leg (same workload on the HUDIFF_X3=1 kernels, reported beside the f32 metric)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HuDiff-Nb line (BASELINE configs[3]) printed beside the metric")
+    ap.add_argument("--attn-only-line", action="store_true", help="also time fp32 GEMMs + split-precision attention kernel (HUDIFF_ATTN_X3=1)")
+    ap.add_argument("--only-main", action="store_true", help="the metric's own leg only (what the PMC passes profile)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--loop-graph", action="store_true", help="the whole T-step loop of a lane as ONE hipGraph (HD_LOOP_GRAPH) "
                     "instead of T replays of the step graph")
@@ -211,61 +214,71 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
                       f"mean T = {mean_T:.1f} steps per sequence"}
 
 
-def split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows, env_name="HUDIFF_X3"):
-    """The same workload on the split-precision GEMM kernels (HUDIFF_X3=1: three fp16 MFMAs with fp32 accumulation per fp32
-    product, hd_kernels.hip.h gemm_x3_k).  Reported BESIDE the metric, never as it: the f32 line above is the product path."""
+PEAK_F16_MATRIX_TFLOPS = 2500.0    # same guide, dense fp16 MFMA; three fp16 MFMAs per fp32 product -> 833.3 fp32-equivalent
+
+
+def secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, x3_env, steps, warmup, first_key=0):
+    """One more timed leg of a workload beside the metric: a model built under ``x3_env`` (e.g. {"HUDIFF_X3": "1"}), the same
+    protocol as the main line (inputs resident, restart + all T steps per sample, device sync on both sides, HIP-event time of
+    the replays), bounded to `steps` samples.  -> (tokens of the last sample, model (still open), dict of raw numbers)."""
     import hudiff_amd
-    B = args.batch
-    prev = os.environ.get(env_name)
-    os.environ[env_name] = "1"
+    B = batch["tokens"].shape[0]
+    Tmax = int(T.max())
+    prev = {k: os.environ.get(k) for k in x3_env}
+    os.environ.update(x3_env)
     try:
         model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
         model.load_state_dict(sd)
     finally:
-        if prev is None:
-            os.environ.pop(env_name, None)
-        else:
-            os.environ[env_name] = prev
-    ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
-    logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
-    dmax = float(np.abs(logits - ref_logits).max())
+        for k, v in prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
                        row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
-    gpu_ms = 0.0
-    watch = None
-    steps = min(args.steps, 3)         # beside the metric: bounded so that a long --steps run spends its time on the f32 line
-    first = args.steps - steps         # the last timed sample carries the same noise key as the f32 line's last one
-    for i in range(first - min(args.warmup, 1), args.steps):
-        model.sample_restart(2023 + 7919 * i)
-        if i == first:
+    gpu_ms, watch, t0 = 0.0, None, 0.0
+    for i in range(-warmup, steps):
+        model.sample_restart(2023 + 7919 * (first_key + i))
+        if i == 0:
             model.sync()
             watch = ClockPowerSampler(local_rank).start()
             t0 = time.perf_counter()
         model.sample_run(0, Tmax)
-        if i >= first:
+        if i >= 0:
             model.sync()
             gpu_ms += model.last_run_ms()[0]
     elapsed = time.perf_counter() - t0
     clock_power = watch.stop() if watch else None
     tokens = model.sample_end()
-    model.close()
-    tf = float(T.sum()) * flops_row * steps / (gpu_ms * 1e-3) / 1e12
-    return tokens, {"value": round(B * steps / elapsed, 4), "unit": "sequences/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
-                    "dtype": "fp32 operands split as fp16 hi + fp16 lo, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate",
-                    "algorithmic_tflops": round(tf, 3), "avg_launch_ms": round(gpu_ms / (steps * Tmax), 4),
-                    # three fp16 MFMAs per fp32 product: matrix-pipe rate against the dense fp16 peak of the guide (2.4 GHz;
-                    # the sample sustains ~2.0 GHz at the 1.4 kW package limit, DESIGN.md section 9)
-                    "roofline": {"bound": "mfma", "achieved": round(3 * tf, 2), "peak": 2500.0,
-                                 "unit": "TFLOP/s (fp16 MFMA, 3 per product)", "frac": round(3 * tf / 2500.0, 4)},
-                    "clock_power": clock_power, "max_abs_dlogit_vs_f32_path": dmax, "dlogit_rows": ref_rows,
-                    "note": "HUDIFF_X3=1 prototype (DESIGN.md section 9): Q|K|V, out-projection, FF and tap GEMMs; the remaining "
-                            "kernels are the f32 ones.  Not the metric."}
+    return tokens, model, {"elapsed": elapsed, "gpu_ms": gpu_ms, "steps": steps, "clock_power": clock_power, "Tmax": Tmax, "B": B,
+                           "precision": model.precision_info()}
 
 
-def live_traffic(args, kind, mode, n_steps=4):
-    """HBM-side bytes per denoiser step from rocprofv3 PMC passes of THIS script (FETCH_SIZE and WRITE_SIZE in separate
-    passes, MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B;
-    unit KB).  Counted from the first token gather on (the once-per-batch static branch is excluded)."""
+def roofline_object(raw, T, flops_row, flops_row_exec, peak, unit, split):
+    """roofline of one leg: algorithmic FLOPs over the HIP-event time of the replays; executed beside it."""
+    tf = float(T.sum()) * flops_row * raw["steps"] / (raw["gpu_ms"] * 1e-3) / 1e12
+    tf_exec = float(raw["B"] * raw["Tmax"]) * flops_row_exec * raw["steps"] / (raw["gpu_ms"] * 1e-3) / 1e12
+    out = {"bound": "mfma", "achieved": round(tf, 3), "peak": round(peak, 2), "unit": unit, "frac": round(tf / peak, 4), "traffic": None,
+           "flops_per_launch": raw["B"] * flops_row, "avg_launch_ms": round(raw["gpu_ms"] / (raw["steps"] * raw["Tmax"]), 4),
+           "executed_tflops": round(tf_exec, 3), "executed_frac": round(tf_exec / peak, 4),
+           "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)}
+    cp = raw.get("clock_power")
+    if cp:
+        pk = peak * cp["sclk_mhz_median"] / 2400.0
+        cp = dict(cp, peak_at_sustained_clock=round(pk, 2), frac_at_sustained_clock=round(tf / pk, 4),
+                  source="amdgpu hwmon freq1_input / power1_input of this GPU, 10 Hz over the timed region")
+        out["clock_power"] = cp
+    if split:
+        out["peak_note"] = ("fp32-equivalent peak of the split route: dense fp16 MFMA peak of the guide (2500 TFLOP/s at 2.4 GHz) / 3 "
+                            "MFMAs per product")
+    return out
+
+
+def live_pmc(args, kind, mode, x3, n_steps=4):
+    """HBM-side bytes per denoiser step and the MFMA pipe's busy fraction from rocprofv3 PMC passes of THIS script (a 4-step
+    one-lane run in a subprocess, --kernel-trace only).  Two passes: `FETCH_SIZE` alone (3 of the 4 TCC slots), then `WRITE_SIZE`
+    with `SQ_VALU_MFMA_BUSY_CYCLES` and `GRBM_GUI_ACTIVE` (SQ and GRBM slots are independent of the TCC's; MI355X_MICROARCH.md "HBM" /
+    "rocprofv3 PMC slots").  FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); unit KB.  Counted from the first token
+    gather on (the once-per-batch static branch is excluded).  mfma_busy = MFMA-busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs):
+    the fraction of all SIMD cycles, launch gaps included, in which the matrix pipe was executing."""
     import csv
     import glob
     import shutil
@@ -275,35 +288,53 @@ def live_traffic(args, kind, mode, n_steps=4):
         return None
     tot = {}
     tmp = tempfile.mkdtemp(prefix="hudiff_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", HUDIFF_X3="1" if x3 else "0")
+    env.pop("HUDIFF_ATTN_X3", None)
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+        for n, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+            out = os.path.join(tmp, f"pass{n}")
+            cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--kind", kind, "--mode", mode, "--batch", str(args.batch),
                    "--dropout", args.dropout, "--data", args.data, "--steps", "1", "--warmup", "0", "--max-t", str(n_steps),
-                   "--no-cpu-baseline", "--lanes", "1", "--traffic", "off"]
+                   "--no-cpu-baseline", "--lanes", "1", "--pmc", "off", "--only-main"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for f in files for r in csv.DictReader(open(f))]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-            started, acc = False, 0.0
+            started = False
             for r in rows:
                 started = started or "embed_tokens_k" in r["Kernel_Name"]
-                if started and r["Counter_Name"] == counter:
-                    acc += float(r["Counter_Value"])
-            tot[counter] = acc
+                if started and r["Counter_Name"] in counters:
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     except Exception as e:                 # profiler absent / refused: the bench line must still appear
-        sys.stderr.write(f"[bench] live PMC traffic pass failed: {e!r}\n")
+        sys.stderr.write(f"[bench] live PMC pass failed: {e!r}\n")
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
+        return None
     rd = 2.0 * tot["FETCH_SIZE"] * 1024.0 / n_steps
     wr = tot["WRITE_SIZE"] * 1024.0 / n_steps
-    return {"traffic": rd + wr, "read_bytes": rd, "write_bytes": wr,
-            "note": f"bytes per denoiser step, live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a "
-                    f"{n_steps}-step one-lane run of this command; FETCH_SIZE x 2 (gfx950), KB -> bytes; L2<->fabric side, "
-                    "Infinity-Cache hits included"}
+    busy = None
+    if tot.get("GRBM_GUI_ACTIVE"):
+        busy = tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (tot["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    return {"traffic": rd + wr, "read_bytes": rd, "write_bytes": wr, "mfma_busy": busy,
+            "note": f"per denoiser step, live: rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (two "
+                    f"passes) over a {n_steps}-step one-lane run of this command; FETCH_SIZE x 2 (gfx950), KB -> bytes; L2<->fabric side, "
+                    "Infinity-Cache hits included; mfma_busy = MFMA-busy cycles / all SIMD cycles of that profiled run"}
+
+
+def attach_pmc(roof, pmc):
+    if pmc is None:
+        return
+    roof["traffic"] = pmc["traffic"]
+    roof["traffic_read_bytes"], roof["traffic_write_bytes"] = pmc["read_bytes"], pmc["write_bytes"]
+    # bytes per launch / measured launch time of the timed region = HBM-side GB/s the path sustains (peak ~8 TB/s: not the limiter)
+    roof["hbm_gbps"] = round(pmc["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
+    roof["hbm_frac_of_8TBps"] = round(roof["hbm_gbps"] / 8000.0, 4)
+    if pmc["mfma_busy"] is not None:
+        roof["mfma_busy"] = round(pmc["mfma_busy"], 4)
+    roof["pmc_note"] = pmc["note"]
 
 
 def relaunch_one_rank_per_gpu(args):
@@ -415,21 +446,73 @@ def main():
     elapsed = time.perf_counter() - t0
     clock_power = watch.stop() if watch else None
     tokens = model.sample_end()
-    split = None
-    if rank == 0 and world == 1 and args.max_t == 0 and not args.no_split_line and os.environ.get("HUDIFF_X3", "0") in ("", "0"):
+    prec_main = model.precision_info()
+    only_main = args.only_main or args.max_t > 0 or world > 1 or force_pg
+    x3_exported = os.environ.get("HUDIFF_X3", "0") not in ("", "0")
+    split = secondary = None
+    t_phase = time.perf_counter()
+
+    def phase(name):
+        nonlocal t_phase
+        now = time.perf_counter()
+        sys.stderr.write(f"[bench] {name}: {now - t_phase:.1f} s\n")
+        t_phase = now
+
+    if rank == 0 and not only_main and not args.no_split_line and not x3_exported:
+        # ---- the same workload on the split-precision kernels, with its own full roofline; reported BESIDE the f32 metric ----
         ref_rows = min(B, 64)          # enough activation rows (>= 8192) for the big-launch kernels on both models
         ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
-        ref_logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023,
-                           row0=rank * B, step=0)
-        x3_tokens, split = split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows)
-        split["rows_with_identical_tokens"] = f"{int((x3_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)"
-        # for the record: the fp32 GEMMs with ONLY the attention kernel in split precision (HUDIFF_ATTN_X3=1)
-        ao_tokens, ao = split_precision_leg(args, kind, cfg, sd, batch, T, Tmax, rank, local_rank, flops_row, ref_logits, ref_rows,
-                                            env_name="HUDIFF_ATTN_X3")
-        split["attention_kernel_only"] = {
-            "value": ao["value"], "unit": "sequences/s", "steps": ao["steps"], "max_abs_dlogit_vs_f32_path": ao["max_abs_dlogit_vs_f32_path"],
-            "rows_with_identical_tokens": f"{int((ao_tokens == tokens).all(1).sum())} of {B}",
-            "note": "fp32 GEMMs + attn_x3_k (HUDIFF_ATTN_X3=1); not the metric"}
+        ref_logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
+        n_split = min(args.steps, 3)
+        x3_tokens, mx, raw = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_X3": "1"}, n_split, min(args.warmup, 1),
+                                           first_key=args.steps - n_split)      # last sample keyed like the f32 line's last
+        lg = mx(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
+        mx.close()
+        roof = roofline_object(raw, T, flops_row, flops_row_exec, PEAK_F16_MATRIX_TFLOPS / 3.0, "TFLOP/s (fp32-equivalent)", split=True)
+        split = {"value": round(B * raw["steps"] / raw["elapsed"], 4), "unit": "sequences/s", "steps": raw["steps"],
+                 "ms_per_step": round(1e3 * raw["elapsed"] / raw["steps"], 3),
+                 "dtype": "fp32 operands split as fp16 hi + fp16 lo, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate", "roofline": roof,
+                 "max_abs_dlogit_vs_f32_path": float(np.abs(lg - ref_logits).max()), "dlogit_rows": ref_rows,
+                 "rows_with_identical_tokens": f"{int((x3_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)",
+                 "precision_info": raw["precision"],
+                 "eligibility": "launches of >= 8192 activation rows take the split-precision kernels (HuDiff-Ab: B >= 29 rows per lane, "
+                                "HuDiff-Nb: B >= 54); smaller launches, the pruned tail's compact GEMMs and the static branch run the f32 kernels; "
+                                "operands with |x| >= 65504 trip the range guard (precision_info.range_fallbacks) and the call is repeated on f32",
+                 "note": "HUDIFF_X3=1 (DESIGN.md section 9).  Not the metric: the top-level value is the f32 path."}
+        phase("split-precision leg")
+        if args.attn_only_line:
+            ao_tokens, ma, rawa = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_ATTN_X3": "1"}, n_split,
+                                                min(args.warmup, 1), first_key=args.steps - n_split)
+            ma.close()
+            split["attention_kernel_only"] = {"value": round(B * rawa["steps"] / rawa["elapsed"], 4), "unit": "sequences/s", "steps": rawa["steps"],
+                                              "rows_with_identical_tokens": f"{int((ao_tokens == tokens).all(1).sum())} of {B}",
+                                              "note": "fp32 GEMMs + attn_x3_k (HUDIFF_ATTN_X3=1); not the metric"}
+            phase("attention-only leg")
+
+    if rank == 0 and not only_main and not args.no_secondary and kind == "ab":
+        # ---- BASELINE configs[3]: HuDiff-Nb on abnativ_select_vhh, plain mask, 256 rows, same protocol -- a secondary object ----
+        ncfg = dict(S.NB_CONFIG)
+        nsd = S.random_state_dict("nb", ncfg, seed=0)
+        nbatch, nreal = make_batch("nb", B, "plain", rank * B, args.data)
+        nT = nbatch["T"].copy()
+        secondary = {}
+        for tag, env in (("f32", {"HUDIFF_X3": "0"}), ("split_precision", {"HUDIFF_X3": "1"})):
+            if tag == "split_precision" and (args.no_split_line or x3_exported):
+                continue
+            ntok, mn, rawn = secondary_leg(args, "nb", "plain", ncfg, nsd, nbatch, nT, rank, local_rank, env, 2, 1)
+            f_alg, f_exec = mn.flops_per_row_forward(), mn.flops_per_row_sample_step()
+            mn.close()
+            pk = PEAK_F32_MATRIX_TFLOPS if tag == "f32" else PEAK_F16_MATRIX_TFLOPS / 3.0
+            secondary[tag] = {"value": round(B * rawn["steps"] / rawn["elapsed"], 4), "unit": "sequences/s", "steps": rawn["steps"],
+                              "ms_per_step": round(1e3 * rawn["elapsed"] / rawn["steps"], 3),
+                              "roofline": roofline_object(rawn, nT, f_alg, f_exec, pk, "TFLOP/s" + ("" if tag == "f32" else " (fp32-equivalent)"),
+                                                          split=tag != "f32"),
+                              "all_tokens_valid": bool(((ntok >= 0) & (ntok <= 21)).all())}
+        secondary = {"metric": "humanized sequences/sec (full T-step sample)" + (" on abnativ_select_vhh" if nreal else ""),
+                     "config": {"workload": f"BASELINE configs[3]: HuDiff-Nb NanoAntiTFNet (17.5M params, L=152), plain mask, batch {B}/GPU, full "
+                                            f"T-step sample (T {int(nT.min())}..{int(nT.max())}, mean {float(nT.mean()):.1f}), dropout {args.dropout}"},
+                     **secondary}
+        phase("HuDiff-Nb secondary line")
 
     # ---- the single collective of the job: gather the final tokens on rank 0 (RCCL over xGMI) ----------
     gathered = [tokens]
@@ -451,14 +534,17 @@ def main():
             assert not (all_tokens == 22).any(), "masked slots left after a full sample"
         seqs = n_gpus * B * args.steps
         value = seqs / elapsed
-        useful_flops = float(T.sum()) * flops_row * args.steps            # per GPU, algorithmic
-        executed_flops = float(B * Tmax) * flops_row_exec * args.steps     # every row is computed every step
-        achieved = useful_flops / (gpu_ms * 1e-3) / 1e12
+        raw_main = {"gpu_ms": gpu_ms, "steps": args.steps, "B": B, "Tmax": Tmax, "clock_power": clock_power}
+        peak_main = PEAK_F16_MATRIX_TFLOPS / 3.0 if x3_exported else PEAK_F32_MATRIX_TFLOPS
+        roof = roofline_object(raw_main, T, flops_row, flops_row_exec, peak_main, "TFLOP/s", split=x3_exported)
+        roof["launch"] = ("one denoiser step = one replay of the captured hipGraph (all kernels of a forward + sampling), HIP events on the "
+                          "library's stream")
         out = {
             "metric": "humanized sequences/sec (full T-step sample)" + (" on HuAb348" if (real and kind == "ab") else ""),
             "value": round(value, 4), "unit": "sequences/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 via fp16 (hi, lo) split, 3 fp16 MFMAs per product (HUDIFF_X3=1 exported)" if x3_exported else "f32",
             "data": (("HuAb348 mouse pairs" if kind == "ab" else "abnativ_select_vhh VHH") +
                      f" ({batch['n_sequences']} sequences of the reference's evaluation CSV, IMGT-slotted by hudiff_amd.numbering into "
                      "hudiff_amd/data/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
@@ -473,47 +559,27 @@ def main():
                        "rows_per_gpu": B, "global_rows": n_gpus * B, "denoiser_steps_per_sample": Tmax,
                        "parallelism": f"rows sharded x{n_gpus}, one RCCL gather of int32 tokens",
                        "process_group": formed},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
-                         "launch": "one denoiser step = one replay of the captured hipGraph (all kernels of a forward "
-                                   "+ sampling), HIP events on the library's stream",
-                         "flops_per_launch": B * flops_row, "avg_launch_ms": round(gpu_ms / (args.steps * Tmax), 4),
-                         "executed_tflops": round(executed_flops / (gpu_ms * 1e-3) / 1e12, 3),
-                         "executed_frac": round(executed_flops / (gpu_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
-                         "executed_over_algorithmic": round(flops_row_exec / flops_row, 4)},
+            "roofline": roof,
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
+            "precision_info": prec_main,
         }
-        if clock_power:
-            # the 157.3 TFLOP/s peak is the 2.4 GHz figure; the package power limit decides the clock the kernels really ran at
-            pk = PEAK_F32_MATRIX_TFLOPS * clock_power["sclk_mhz_median"] / 2400.0
-            clock_power.update({"peak_at_sustained_clock": round(pk, 2), "frac_at_sustained_clock": round(achieved / pk, 4),
-                                "source": "amdgpu hwmon freq1_input / power1_input of this GPU, 10 Hz over the timed region"})
-            out["roofline"]["clock_power"] = clock_power
-        # HBM-side traffic per launch: live PMC passes of this very command (subprocess, after the timed region), else the
-        # committed passes of the round (profiles/r02/pmc_traffic.json, stamped with the commit they were taken at)
-        if args.traffic in ("auto", "live") and n_gpus == 1 and args.max_t == 0:
-            lt = live_traffic(args, kind, mode)
-            if lt is not None:
-                out["roofline"]["traffic"] = lt["traffic"]
-                out["roofline"]["traffic_read_bytes"], out["roofline"]["traffic_write_bytes"] = lt["read_bytes"], lt["write_bytes"]
-                out["roofline"]["traffic_note"] = lt["note"]
-        if out["roofline"]["traffic"] is None and args.traffic in ("auto", "file"):
-            try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
-                c = tr["config"]      # measured with one lane; the bytes do not depend on how the batch is split into lanes
-                if (c["kind"], c["rows_per_gpu"], c["dropout"]) == (kind, B, args.dropout):
-                    out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = ("bytes per denoiser step, profiles/r02/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE), "
-                                                       f"taken at commit {tr.get('git_head', '?')}")
-            except Exception:
-                pass
+        # HBM-side traffic, HBM GB/s and MFMA-busy per launch: live PMC passes of this very command (subprocess, after the timed region)
+        if args.pmc in ("auto", "live") and not only_main:
+            attach_pmc(out["roofline"], live_pmc(args, kind, mode, x3=x3_exported))
+            phase("PMC passes (f32)")
+            if split is not None:
+                attach_pmc(split["roofline"], live_pmc(args, kind, mode, x3=True))
+                phase("PMC passes (split precision)")
         if split is not None:
             out["split_precision"] = split
+        if secondary is not None:
+            out["secondary"] = {"hudiff_nb_configs3": secondary}
         if args.max_t > 0:
             out["truncated"] = f"--max-t {args.max_t}: NOT the metric (profiling run)"
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline and n_gpus == 1 and not args.only_main:
             out["cpu_baseline"] = cpu_baseline(kind, cfg, sd, mode, args.cpu_rows, args.cpu_steps, float(batch["T"].mean()),
                                                args.cpu_impl, args.data)
+            phase("CPU baseline")
         print(json.dumps(out), flush=True)
     model.close()
     if dist is not None:
