@@ -171,3 +171,52 @@ def test_edge_cases():
     d, c = N.number_sequence_builtin(vl6)
     assert c == "L" and (d["80"], d["81"], d["82"], d["83"]) == ("I", "D", "S", "S")
     assert "".join(d[str(p)] for p in range(105, 118)) == "QSYDS---SNHVV"
+
+
+def test_validity_predicate_panel():
+    """f-2 (VERDICT r2 "Next" #6c): the nanobody sampler keeps a sample only if ``abnumber.Chain(g_h, scheme='imgt')`` parses
+    (nanosample.py:338-353) -- an ANARCI / HMMER score threshold that cannot be evaluated offline.  The stand-in
+    ``is_variable_domain`` (complete numbered domain: C23, C104, residues at 41 and at the J columns 118 / 119 / 121) is pinned here on a panel of what a
+    sampler can emit: it must ACCEPT every VHH of the reference's evaluation set, the same domains with the substitutions a
+    framework re-sample makes, and domains with leader / tag flanks; it must REJECT the classes abnumber is known to refuse --
+    no recognisable variable domain: half domains, a domain whose C-terminal half is out of frame, a domain cut inside its
+    CDR3, a reversed domain, low-complexity and random strings, the empty string.  Where the two can legitimately differ is
+    stated: a domain that lost a conserved cysteine still scores as a domain for an HMM, the stand-in rejects it (stricter)."""
+    from hudiff_amd import evalsets as E
+    rng = np.random.default_rng(3)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    vhh = E.sequences("vhh")
+    assert len(vhh) == 300
+    assert all(N.is_variable_domain(s) for s in vhh)                          # every real VHH passes
+    cap = KNOWN["caplacizumab_VHH"][0]
+    d, _ = N.number_sequence_builtin(cap)
+    pos_of = []                                                                # IMGT position of every residue of `cap`, in order
+    for key in sorted(d, key=lambda k: (int("".join(c for c in k if c.isdigit())), k)):
+        if d[key] != "-":
+            pos_of.append(int("".join(c for c in key if c.isdigit())))
+    assert len(pos_of) == len(cap)
+    anchors = {23, 41, 104, 118, 119, 121}
+    for _ in range(40):                                                        # framework re-samples that keep the anchors
+        s = list(cap)
+        for i in rng.choice(len(s), size=12, replace=False):
+            if pos_of[i] not in anchors and not (27 <= pos_of[i] <= 38 or 56 <= pos_of[i] <= 65 or 105 <= pos_of[i] <= 117):
+                s[i] = aa[rng.integers(20)]
+        assert N.is_variable_domain("".join(s))
+    assert N.is_variable_domain("MKYLLPTAAAGLLLLAAQPAMA" + cap + "HHHHHH")      # pelB leader + His tag
+    half = len(cap) // 2
+    rejected = {
+        "N-terminal half": cap[:half], "C-terminal half": cap[half:], "cut inside CDR3": cap[:-30],
+        "second half out of frame": cap[:half] + "".join(aa[rng.integers(20)] for _ in range(len(cap) - half)),
+        "reversed": cap[::-1], "poly-alanine": "A" * 120, "random": "".join(aa[rng.integers(20)] for _ in range(120)),
+        "empty": "", "short peptide": "EVQLVESGGG",
+    }
+    for why, s in rejected.items():
+        assert not N.is_variable_domain(s), why
+    # stricter than an HMM threshold, on purpose and documented: a lost disulfide cysteine -> rejected; the hallmark positions
+    # 41 / 118 / 119 may vary (natural VHHs do: G41, R41, E118-T119, ...)
+    for p in (23, 104):
+        i = pos_of.index(p)
+        assert not N.is_variable_domain(cap[:i] + "A" + cap[i + 1:])
+    for p in (41, 118, 119):
+        i = pos_of.index(p)
+        assert N.is_variable_domain(cap[:i] + "R" + cap[i + 1:])
