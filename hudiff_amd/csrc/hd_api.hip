@@ -79,6 +79,7 @@ struct Workspace {
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float *S1 = nullptr, *YX = nullptr, *ATX = nullptr;      // split-precision route: act(LN(x)) of a ByteNet block's input; split copies of Y / AT, [M,D]
     float2* ST = nullptr;
+    int* SYNC = nullptr;                                     // ln_sync meeting counters, 2 ints per (segment, M tile), zero between launches
     float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
     int part_next = 0;                                       // buffer the next producing GEMM writes
     const float2* part_last = nullptr; int part_last_pw = 0; // what the last producing GEMM wrote (for its consumer)
@@ -712,7 +713,11 @@ static HdStatus ensure_ws(HdModel* m, int B) {
     HD_TRY(dalloc(ws, &ws.EXTRA, M * d)); HD_TRY(dalloc(ws, &ws.POS, M * d)); HD_TRY(dalloc(ws, &ws.PH, M * 2 * d));
     HD_TRY(dalloc(ws, &ws.ST, M)); HD_TRY(dalloc(ws, &ws.PART[0], M * PART_STRIDE)); HD_TRY(dalloc(ws, &ws.PART[1], M * PART_STRIDE));
     HD_TRY(dalloc(ws, &ws.LOGITS, M * m->cfg.n_tokens));
-    if (m->x3) { HD_TRY(dalloc(ws, &ws.S1, M * D)); HD_TRY(dalloc(ws, &ws.YX, M * D)); HD_TRY(dalloc(ws, &ws.ATX, M * D)); }
+    if (m->x3) {
+        HD_TRY(dalloc(ws, &ws.S1, M * D)); HD_TRY(dalloc(ws, &ws.YX, M * D)); HD_TRY(dalloc(ws, &ws.ATX, M * D));
+        HD_TRY(dalloc(ws, &ws.SYNC, (size_t)8 * 0x4000));
+        HIP_TRY(hipMemsetAsync(ws.SYNC, 0, (size_t)8 * 0x4000 * sizeof(int), cur(m).stream));
+    }
     HD_TRY(dalloc(ws, &ws.ATc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Xc, (size_t)B * D)); HD_TRY(dalloc(ws, &ws.Qc, (size_t)B * A));
     HD_TRY(dalloc(ws, &ws.Oc, (size_t)B * A)); HD_TRY(dalloc(ws, &ws.F1c, (size_t)B * Fd)); HD_TRY(dalloc(ws, &ws.STc, (size_t)B));
     HD_TRY(dalloc(ws, &ws.PW, (size_t)B * m->cfg.nhead * 320)); HD_TRY(dalloc(ws, &ws.YV, (size_t)B * m->cfg.nhead * m->D));
@@ -831,7 +836,8 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     // nothing on the fp32 one (HUDIFF_ST_NT=1 turns them on there)
     static const int st_nt = [] { const char* e = getenv("HUDIFF_ST_NT"); return e ? atoi(e) : 0; }();
     p.st_nt = big ? st_nt : 0;
-    if (stats_out != STATS_NONE || apply) p.part = ws.PART[ws.part_next];
+    if (stats_out != STATS_NONE || apply || p.ln_sync) p.part = ws.PART[ws.part_next];
+    if (p.ln_sync) p.sync_ctr = ws.SYNC;
     static const int small_tiles = [] { const char* e = getenv("HUDIFF_GEMM_SMALL"); return e ? atoi(e) : 1536; }();
     const long tiles128 = ((rows + 127) / 128) * ((p.N + 127) / 128);
     // the BK = 16 kernels assume whole k tiles and 32-bit byte offsets inside every operand (gemm_k, FAST)
@@ -864,6 +870,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         const long t256 = (rows0 + 255) / 256 + (rows1 + 255) / 256;
         int shape = (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) ? 512 : 128;
         if (force == 128 || force == 256 || (force == 512 && q.N % 256 == 0)) shape = force;
+        if (q.ln_sync) shape = 128;                     // the meeting epilogue exists in the 4-wave 128 x 128 instantiation only
         const int bm = shape == 128 ? 128 : 256, bn = shape == 512 ? 256 : 128;
         q.tiles0 = (rows0 + bm - 1) / bm;
         q.tiles_m = q.tiles0 + (rows1 + bm - 1) / bm;
@@ -923,44 +930,65 @@ static void set_drop(GemmP& p, const Drop& dr) {
 // Where the LayerNorm statistics of a GEMM's input rows come from
 enum XStats { X_FINAL = 0,      // ws.ST already holds (mean, rstd)
               X_PARTIALS = 1,   // the previous GEMM left slice partials (merged in the prologue)
-              X_NONE = 2 };     // nothing yet: run row_stats_k
+              X_NONE = 2,       // nothing yet: run row_stats_k
+              X_S1 = 3 };       // split-precision route: the previous block already wrote act(LN1(x)) in split form into ws.S1
 
 // One ByteNet block:  out = dropout(x + PFF2(act(LN(conv(act(LN(PFF1(act(LN(x))))))))))   [+ extra]
 // LayerNorm statistics travel with the data: every GEMM epilogue leaves (mean, M2) slice partials of the rows it
 // wrote and the next GEMM merges them in its prologue; in front of the tap GEMM, LayerNorm + activation are applied
 // once in place (ln_apply_k).  want_out_stats: leave partials of `out` for the next block's first GEMM.
+// ln_sync on / off (HUDIFF_X3_LNSYNC, default on): the split-precision ByteNet GEMMs normalise + activate + split their own
+// output rows (GemmP::ln_sync) instead of leaving that to a separate ln_apply_k pass over HBM
+static int x3_lnsync_level() {
+    // 0 off, 1 the two inner GEMMs of a block (h1, h2), 2 also the block's last GEMM (writes the NEXT block's first operand)
+    static const int lv = [] { const char* e = getenv("HUDIFF_X3_LNSYNC"); return e ? atoi(e) : 2; }();
+    return lv;
+}
+static bool x3_lnsync() { return x3_lnsync_level() > 0; }
+
+// `next`: the block that follows in the same stack (same widths) when it will also take the split-precision route and reads
+// exactly `out` (ldo == din, no columns beside it): this block's last GEMM then writes act(LN1_next(out)) in split form into ws.S1
+// itself, and the next call passes x_stats = X_S1 (its first operand is ready).
 static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din, int dh, int act,
                           const float* x, int ldx, float* h1, float* h2, float* out, int ldo,
                           const Drop& dr, const float* extra, int lde, XStats x_stats, bool want_out_stats,
-                          float* out_split = nullptr) {
+                          float* out_split = nullptr, const ByteNetW* next = nullptr) {
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
     if (x_stats == X_NONE) launch_stats(m, x, ldx, din, rows, cur(m).stream);
     if (x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && x3_use(m, sg, w.w3x) && cur(m).ws.S1) {
-        // Split-precision route.  Every GEMM operand is normalised + activated ONCE by ln_apply_k, which also writes it in
-        // split (hi, lo) form -- out of place for x (the residual needs its fp32 rows), in place for h1 and h2 -- and the three
-        // projections run on gemm_x3_k without a prologue.  (The fp32 route recomputes LayerNorm + activation in every
-        // N tile's prologue, which costs more than the MFMAs once those are three fp16 instructions.)
+        // Split-precision route.  Every GEMM operand is act(LN(.)) of the previous result in split (hi, lo) form and the three
+        // projections run on gemm_x3_k without a prologue.  (The fp32 route recomputes LayerNorm + activation in every N tile's
+        // prologue, which costs more than the MFMAs once those are three fp16 instructions.)  Who writes the operand:
+        //   ln_sync on  : the producing GEMM itself -- the blocks of an M tile exchange their LayerNorm partials and normalise the
+        //                 rows they still hold in registers (GemmP::ln_sync); h1 / h2 never exist as fp32 rows.  Only the first block
+        //                 of a stack still needs one ln_apply_k pass for x (its producer is not a GEMM of this kind).
+        //   ln_sync off : ln_apply_k, one HBM round trip per operand (out of place for x, in place for h1 / h2).
         Workspace& ws = cur(m).ws;
         hipStream_t st = cur(m).stream;
         const int seg1 = sg.nseg > 1 ? sg.base[1] : rows;
-        const bool from_part = x_stats == X_PARTIALS;
-        hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
-                           ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
-                           w.ln1_g, w.ln1_b, din, seg1, act, 1, (const RunState*)cur(m).rs);
+        const bool sync = x3_lnsync() && ws.SYNC;
+        if (x_stats != X_S1) {
+            const bool from_part = x_stats == X_PARTIALS;
+            hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
+                               ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
+                               w.ln1_g, w.ln1_b, din, seg1, act, 1, (const RunState*)cur(m).rs);
+        }
         GemmP p = base_gemm(m, sg);
         p.A = ws.S1; p.lda = din; p.W = w.w1; p.bias = w.b1; p.C = h1; p.ldc = dh; p.N = dh; p.Kc = din;
         p.w_stride = (long)din * dh; p.n_stride = dh; p.k_stride = din;
         const LnApply ap2{w.ln2_g, w.ln2_b, dh, act, 1};
         use_x3(p, w.w1x);
-        launch_gemm(m, p, false, true, STATS_NONE, &ap2);
+        if (sync) { p.ln_sync = 1; p.C = nullptr; p.S = h1; p.gamma2 = w.ln2_g; p.beta2 = w.ln2_b; p.act2 = act; p.k2_stride = dh; }
+        launch_gemm(m, p, false, true, STATS_NONE, sync ? nullptr : &ap2);
 
         p = base_gemm(m, sg);
         p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
         p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
         const LnApply ap3{w.ln3_g, w.ln3_b, dh, act, 1};
         use_x3(p, w.wcx);
-        launch_gemm(m, p, true, true, STATS_NONE, &ap3);
+        if (sync) { p.ln_sync = 1; p.C = nullptr; p.S = h2; p.gamma2 = w.ln3_g; p.beta2 = w.ln3_b; p.act2 = act; p.k2_stride = dh; }
+        launch_gemm(m, p, true, true, STATS_NONE, sync ? nullptr : &ap3);
 
         p = base_gemm(m, sg);
         p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
@@ -969,6 +997,7 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
         p.C2 = out_split;
         use_x3(p, w.w3x);
         set_drop(p, dr);
+        if (sync && next) { p.ln_sync = 1; p.S = ws.S1; p.gamma2 = next->ln1_g; p.beta2 = next->ln1_b; p.act2 = act; p.k2_stride = din; }
         launch_gemm(m, p, false, true, want_out_stats ? STATS_PARTIALS : STATS_NONE);
         return;
     }
@@ -1129,8 +1158,11 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
+        // split-precision route with ln_sync: block n's last GEMM writes block n + 1's first operand (x_stats = X_S1 then)
+        const bool chain = x3_lnsync_level() > 1 && ws.SYNC && x3_use(m, sg, m->enc[n].w1x) && x3_use(m, sg, m->enc[n].wcx) && x3_use(m, sg, m->enc[n].w3x);
         bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
-                      last ? ws.EXTRA : nullptr, d, n == 0 ? X_FINAL : X_PARTIALS, /*want_out_stats=*/!last);
+                      last ? ws.EXTRA : nullptr, d, n == 0 ? X_FINAL : (chain ? X_S1 : X_PARTIALS), /*want_out_stats=*/!last,
+                      nullptr, (chain && !last) ? &m->enc[n + 1] : nullptr);
     }
     if (m->debug_stop_after == 1) return HD_OK;
     const bool ax3 = att_x3(m, sg);
@@ -1139,9 +1171,10 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
         // x3: the last block also leaves Y in split form for the first attention's Q|K|V projection
+        const bool chain = x3_lnsync_level() > 1 && ws.SYNC && x3_use(m, sg, m->conv[n].w1x) && x3_use(m, sg, m->conv[n].wcx) && x3_use(m, sg, m->conv[n].w3x);
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
-                      n == 0 ? X_NONE : X_PARTIALS, /*want_out_stats=*/n + 1 < c.dual_layers,
-                      (ax3 && n + 1 == c.dual_layers) ? ws.YX : nullptr);
+                      n == 0 ? X_NONE : (chain ? X_S1 : X_PARTIALS), /*want_out_stats=*/n + 1 < c.dual_layers,
+                      (ax3 && n + 1 == c.dual_layers) ? ws.YX : nullptr, (chain && n + 1 < c.dual_layers) ? &m->conv[n + 1] : nullptr);
     }
     for (int n = 0; n < c.cs_layers; ++n) {
         if (m->debug_stop_after == 2 + n) return HD_OK;
@@ -1262,6 +1295,8 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
     if (split_active(m)) {          // range guard: an operand of a split-precision kernel left the fp16 range -> fp32 kernels
         RunState h{};
         HIP_TRY(hipMemcpy(&h, cur(m).rs, sizeof(h), hipMemcpyDeviceToHost));
+        if (h.pad[2]) return fail(HD_ERR_STATE, "hd_forward: a GEMM's ln_sync meeting failed (%s); set HUDIFF_X3_LNSYNC=0",
+                                  (h.pad[2] & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
         if (h.pad[1]) {
             suspend_split(m);
             return hd_forward(m, tokens, region, chain, B, flags, seed, row0, step, enc_masks, conv_masks, logits);
@@ -1500,6 +1535,8 @@ static HdStatus sample_collect(HdModel* m, int32_t* tokens, bool* numeric, bool*
         HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
         if (h.pad[0]) *numeric = true;
         if (h.pad[1]) *range = true;
+        if (h.pad[2]) return fail(HD_ERR_STATE, "hd_sample: a GEMM's ln_sync meeting failed (%s); set HUDIFF_X3_LNSYNC=0",
+                                  (h.pad[2] & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
     }
     return HD_OK;
 }

@@ -209,6 +209,14 @@ struct GemmP {
     const uint8_t* drop_mask;         // [B, L, N] keep-mask (DROP_INJECT)
     const RunState* rs;
     float2* part; long part_rows;     // optional [PART_STRIDE][part_rows] LayerNorm (mean, M2) slice partials of the OUTPUT rows
+    // ln_sync (gemm_x3_k only): LayerNorm + activation of the OUTPUT rows applied by this launch itself.  A row's statistics need
+    // all of its N columns, i.e. the tiles_n blocks of its M tile; those run at the same time on one XCD (consecutive slots of
+    // the XCD-aware tile order), so after leaving their slice partials in `part` they meet at a counter in `sync_ctr` (four ints
+    // per M tile: arrivals, departures, XCC ids seen, spare; self-resetting), merge the partials and write   S = act(LN(row; gamma2, beta2))   in
+    // split form from the values they still hold in registers -- instead of a separate ln_apply_k pass that reads the fp32
+    // rows back from HBM and writes S.  C may be null (S is the only output).  A wait that exceeds its budget raises
+    // RunState::pad[2] (the forward then fails with HD_ERR_STATE) -- never a hang.
+    int ln_sync; int* sync_ctr; float* S; const float* gamma2; const float* beta2; int act2; int k2_stride;
     // geometry
     Segs sg;
     int tiles0;                       // number of M tiles of segment 0
@@ -290,10 +298,13 @@ __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll
 // the epilogue is a third of the matrix time of the short-K projections there).
 enum : int { EPI_FOLD = 1, EPI_ACT = 2, EPI_RESID = 4, EPI_DROP = 8, EPI_EXTRA = 16, EPI_PART = 32, EPI_CSPLIT = 64, EPI_C2 = 128,
              EPI_ALL = 255,
-             EPI_X3 = 256 };      // set by gemm_x3_k on every mask: acc_scale always applies, stores are non-temporal
+             EPI_X3 = 256,        // set by gemm_x3_k on every mask: acc_scale always applies, stores are non-temporal
+             EPI_LNSYNC = 512 };  // GemmP::ln_sync: the blocks of an M tile exchange their LayerNorm partials and write the NEXT GEMM's
+                                  // operand -- act(LN(output row)) in split form -- themselves (see gemm_epilogue)
 __host__ __device__ __forceinline__ int epi_needs(const GemmP& p) {
     return (p.ln_fold ? EPI_FOLD : 0) | (p.epi_act ? EPI_ACT : 0) | (p.resid ? EPI_RESID : 0) | (p.drop_mode != DROP_NONE ? EPI_DROP : 0) |
-           (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0);
+           (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0) |
+           (p.ln_sync ? EPI_LNSYNC : 0);
 }
 template <int BM, int BN, int WM, int WN, int F = EPI_ALL>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
@@ -315,6 +326,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int epi_act = (F & EPI_ACT) ? p.epi_act : 0;
     const bool has_resid = (F & EPI_RESID) && p.resid, has_extra = (F & EPI_EXTRA) && p.extra, has_part = (F & EPI_PART) && p.part;
     const bool ln_fold = (F & EPI_FOLD) && p.ln_fold, c_split = (F & EPI_CSPLIT) && p.c_split, has_c2 = (F & EPI_C2) && p.C2;
+    const bool ln_sync = (F & EPI_LNSYNC) && p.ln_sync;
+    const bool has_c = !(F & EPI_LNSYNC) || p.C != nullptr;      // an ln_sync launch may have S as its only output
     float acc_scale = p.acc_scale;
     asm volatile("" : "+v"(acc_scale));      // kept in a VGPR: the compiler otherwise re-loads it from the kernel arguments per row group
     if (drop_mode == DROP_GEN) {
@@ -344,6 +357,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const int nv = min(WTN, N - (n0 + wn * WTN));     // valid columns of this wave's slice (uniform)
     const float inv_nv = 1.0f / (float)max(nv, 1);
     float vmax = 0.f;                                 // largest |value| this lane wrote in split form (range guard)
+    f32x4 keep[(F & EPI_LNSYNC) ? TM : 1][(F & EPI_LNSYNC) ? 32 / RPI : 1];     // ln_sync: the finished output values, for the second pass
+    // fp32 row and / or split copy of the finished values of one 4-row group
+    auto store_out = [&](const f32x4 v, const bool valid, const int g0) {
+        if (!c_split && has_c) {
+                const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
+                    p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                if ((F & EPI_X3) || p.st_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
+            }
+            if (c_split || has_c2) {
+                // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                h16x4 hh, ll;
+                split4(v, hh, ll);
+                if ((HD_GUARD_MASK & 1) && valid) vmax = absmax4(vmax, v);
+                float* base = c_split ? p.C : p.C2;
+                const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
+                const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
+                if ((F & EPI_X3) || p.st_nt) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
+                }
+            }
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // residual values of this pass are requested up front (each lane reads exactly the elements it will
@@ -410,31 +452,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     const_cast<float*>(p.extra) + (long)(rbase + g0) * p.lde, 0, BUF_MAX, 0x00020000);
                 v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, (int)(valid ? x_vo : BUF_OFF), 0, 0));
             }
-            if (!c_split) {
-                const __amdgpu_buffer_rsrc_t cs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.C + (long)(rbase + g0) * p.ldc, 0, BUF_MAX, 0x00020000);
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                if ((F & EPI_X3) || p.st_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 2);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cs, (int)(valid ? c_vo : BUF_OFF), 0, 0);
-            }
-            if (c_split || has_c2) {
-                // split form of the row (hi plane, then lo plane, N halfs each) for a gemm_x3_k consumer
-                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                h16x4 hh, ll;
-                split4(v, hh, ll);
-                if ((HD_GUARD_MASK & 1) && valid) vmax = absmax4(vmax, v);
-                float* base = c_split ? p.C : p.C2;
-                const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
-                const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
-                if ((F & EPI_X3) || p.st_nt) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
-                }
-            }
+            if constexpr ((F & EPI_LNSYNC) != 0) keep[i][it] = v;
+            // (an ln_sync launch stores after it has published its partials: the stores then overlap the wait for the other tiles)
+            if (!((F & EPI_LNSYNC) && ln_sync)) store_out(v, valid, g0);
             if (has_part) {
                 // LayerNorm statistics of the row this GEMM just produced, for its consumer: every wave owns a
                 // WTN-wide column slice of the row (LPR lanes x 4 columns); it reduces (mean, sum of squared
@@ -463,6 +483,132 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const int lrow = m0 + wm * WTM + r;
             if (lrow < seg_rows && nv > 0)
                 p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
+        }
+    }
+    if constexpr ((F & EPI_LNSYNC) != 0) {
+        if (ln_sync) {
+            float2* wst = reinterpret_cast<float2*>(stage);              // (mean, rstd) of this wave's WTM rows; the staging slice is free now
+            if (p.tiles_n == 1) {
+                // ---- one N tile holds whole rows: the WN slice partials of a row are all in this block's LDS ----------------
+                __syncthreads();
+                const float2* allp = reinterpret_cast<const float2*>(smem + EPI_FLOATS);
+                for (int r = lane; r < WTM; r += 64) {
+                    float mean = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) mean += allp[(wm * WN + j) * WTM + r].x * (float)min(WTN, N - j * WTN);
+                    mean /= (float)N;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float2 pr = allp[(wm * WN + j) * WTM + r];
+                        const float d = pr.x - mean;
+                        m2 += pr.y + (float)min(WTN, N - j * WTN) * d * d;
+                    }
+                    wst[r] = make_float2(mean, 1.0f / sqrtf(m2 / (float)N + 1e-5f));
+                }
+                __syncthreads();
+            } else {
+            // ---- meet the other N tiles of this M tile ------------------------------------------------------------------
+            // All tiles_n blocks of an M tile sit on ONE XCD (XCD-aware tile order) and therefore behind one L2: a store that has
+            // left the CU (vmcnt(0): the vector L1 is write-through) is visible to any load that bypasses the reader's L1.  So the
+            // hand-over needs no device-scope fence -- on gfx950 that is a write-back + invalidate of the XCD's whole L2, measured at
+            // 2x the time of the entire step when every block did it -- only this wave's stores drained before the arrival is
+            // counted, and L1-bypassing (agent-scope, relaxed) loads of the partials afterwards.  The one-XCD premise is an
+            // observed property of the dispatcher, so it is CHECKED: every block ORs its XCC id into the tile's third counter and
+            // a tile whose blocks saw more than one id raises RunState::pad[2] (the host then refuses the result).
+            // Nothing but the partials has been stored so far (loads and stores share one in-order counter on this ISA: bulk
+            // stores ahead of the polls and of the partial loads would put their whole drain time into the meeting).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);                               // vmcnt(0): this wave's partial stores have reached the L2
+            __syncthreads();
+            int* ctr = p.sync_ctr + 4 * (seg * 0x4000 + m0 / BM);       // (arrivals, departures, XCC-id mask, -) of this M tile
+            if (tid == 0) {
+                const int xcc = __builtin_amdgcn_s_getreg(6164) & 15;    // HW_REG_XCC_ID[3:0]
+                __hip_atomic_fetch_or(ctr + 2, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int budget = 1 << 20;                                    // ~1 s of polling: far beyond any launch; then give up loudly
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.tiles_n && --budget > 0)
+                    __builtin_amdgcn_s_sleep(1);
+                const int seen = __hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (budget <= 0 || (seen & (seen - 1))) atomicOr(const_cast<uint32_t*>(&p.rs->pad[2]), budget <= 0 ? 1u : 2u);
+            }
+            __syncthreads();
+            // ---- (mean, rstd) of this wave's WTM rows from ALL slices of the row: lane r merges row r (Chan et al.) -----
+            const int P = p.tiles_n * WN;
+            constexpr int PMAX = 16;                                     // N <= 1024 with 64-wide slices
+            for (int r = lane; r < WTM; r += 64) {
+                const int lrow = m0 + wm * WTM + r;
+                float2 st = make_float2(0.f, 0.f);
+                if (lrow < seg_rows) {
+                    const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(p.part) + rbase + lrow;
+                    unsigned long long u[PMAX];
+#pragma unroll
+                    for (int sl = 0; sl < PMAX; ++sl)                    // all loads in flight together (they bypass the L1)
+                        if (sl < P) u[sl] = __hip_atomic_load(pp + (long)sl * p.part_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    float mean = 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < PMAX; ++sl)
+                        if (sl < P) mean += __uint_as_float((uint32_t)u[sl]) * (float)min(WTN, N - sl * WTN);
+                    mean /= (float)N;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < PMAX; ++sl)
+                        if (sl < P) {
+                            const float d = __uint_as_float((uint32_t)u[sl]) - mean;
+                            m2 += __uint_as_float((uint32_t)(u[sl] >> 32)) + (float)min(WTN, N - sl * WTN) * d * d;
+                        }
+                    st = make_float2(mean, 1.0f / sqrtf(m2 / (float)N + 1e-5f));
+                }
+                wst[r] = st;
+            }
+            __syncthreads();                                             // every wave has read the partials it needs ...
+            if (tid == 0) {                                              // ... so this block may leave; the last one resets the counters
+                if (__hip_atomic_fetch_add(ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.tiles_n - 1) {
+                    __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ctr + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            }
+            // ---- the launch's own outputs (fp32 rows, split copy) go out now, behind the meeting ------------------------------
+            if (has_c || has_c2 || c_split) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int g0 = wrow0 + 32 * i + it * RPI;
+                        store_out(keep[i][it], g0 + e_r < seg_rows && col_ok, g0);
+                    }
+                if (c_split || has_c2) raise_range_flag(p.rs, vmax);
+            }
+            // ---- second pass: S = act(LN(row)) in split form, from the values kept in registers ------------------------
+            const float* __restrict__ g2 = p.gamma2 + seg * p.k2_stride;
+            const float* __restrict__ b2 = p.beta2 + seg * p.k2_stride;
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv2 = {0.f, 0.f, 0.f, 0.f};
+            if (col_ok) { gv = *reinterpret_cast<const f32x4*>(g2 + col); bv2 = *reinterpret_cast<const f32x4*>(b2 + col); }
+            float smax = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int rr = it * RPI + e_r;
+                    const int g0 = wrow0 + 32 * i + it * RPI;                   // uniform
+                    const bool valid = g0 + e_r < seg_rows && col_ok;
+                    const float2 st = wst[32 * i + rr];
+                    f32x4 w;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = act_f((keep[i][it][c] - st.x) * st.y * gv[c] + bv2[c], p.act2);
+                    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    h16x4 hh, ll;
+                    split4(w, hh, ll);
+                    if (valid) smax = absmax4(smax, w);
+                    const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(p.S + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
+                    const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
+                }
+            }
+            raise_range_flag(p.rs, smax);
         }
     }
 }
@@ -1033,9 +1179,16 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     }
     // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
     const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
-    const int need = p.x3_abl & 64 ? EPI_ALL : epi_needs(p);
+    const int need = p.x3_abl & 64 ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);
 #define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
-    if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
+    if (need & EPI_LNSYNC) {
+        // (only the 4-wave 128 x 128 instantiation is ever launched with ln_sync; the others keep the code out)
+        if constexpr (NW == 4) {
+            if (!(need & ~(EPI_PART | EPI_LNSYNC))) HD_EPI(EPI_PART | EPI_LNSYNC);
+            else HD_EPI(EPI_ALL | EPI_LNSYNC);
+        }
+    }
+    else if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
     else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
     else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
     else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
