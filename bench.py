@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-split-line", action="store_true",
                     help="skip the extra `split_precision` leg (same workload on the HUDIFF_X3=1 kernels, reported beside the f32 metric)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HuDiff-Nb line (BASELINE configs[3]) printed beside the metric")
-    ap.add_argument("--attn-only-line", action="store_true", help="also time fp32 GEMMs + split-precision attention kernel (HUDIFF_ATTN_X3=1)")
+    ap.add_argument("--no-all-fp32-line", action="store_true", help="skip the `all_fp32_kernels` leg (HUDIFF_ATTN_X3=0: attn_k instead of attn_x3_k)")
     ap.add_argument("--only-main", action="store_true", help="the metric's own leg only (what the PMC passes profile)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--loop-graph", action="store_true", help="the whole T-step loop of a lane as ONE hipGraph (HD_LOOP_GRAPH) "
@@ -480,14 +480,20 @@ def main():
                                 "operands with |x| >= 65504 trip the range guard (precision_info.range_fallbacks) and the call is repeated on f32",
                  "note": "HUDIFF_X3=1 (DESIGN.md section 9).  Not the metric: the top-level value is the f32 path."}
         phase("split-precision leg")
-        if args.attn_only_line:
-            ao_tokens, ma, rawa = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_ATTN_X3": "1"}, n_split,
-                                                min(args.warmup, 1), first_key=args.steps - n_split)
-            ma.close()
-            split["attention_kernel_only"] = {"value": round(B * rawa["steps"] / rawa["elapsed"], 4), "unit": "sequences/s", "steps": rawa["steps"],
-                                              "rows_with_identical_tokens": f"{int((ao_tokens == tokens).all(1).sum())} of {B}",
-                                              "note": "fp32 GEMMs + attn_x3_k (HUDIFF_ATTN_X3=1); not the metric"}
-            phase("attention-only leg")
+    all_fp32 = None
+    if rank == 0 and not only_main and not args.no_all_fp32_line and not x3_exported and os.environ.get("HUDIFF_ATTN_X3", "1") != "0":
+        # ---- every kernel fp32 (HUDIFF_ATTN_X3=0: attn_k, fp32 16x16x4 MFMA, instead of the split-precision attention core) --------
+        n_f = min(args.steps, 2)
+        f_tokens, mf, rawf = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_X3": "0", "HUDIFF_ATTN_X3": "0"}, n_f,
+                                           min(args.warmup, 1), first_key=args.steps - n_f)
+        mf.close()
+        all_fp32 = {"value": round(B * rawf["steps"] / rawf["elapsed"], 4), "unit": "sequences/s", "steps": rawf["steps"],
+                    "ms_per_step": round(1e3 * rawf["elapsed"] / rawf["steps"], 3), "dtype": "f32 (every kernel: fp32 MFMA)",
+                    "roofline": roofline_object(rawf, T, flops_row, flops_row_exec, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", split=False),
+                    "rows_with_identical_tokens": f"{int((f_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)",
+                    "precision_info": rawf["precision"],
+                    "note": "HUDIFF_ATTN_X3=0: the round-1/2 product path, attn_k in place of attn_x3_k; printed so that the two can be read side by side"}
+        phase("all-fp32-kernels leg")
 
     if rank == 0 and not only_main and not args.no_secondary and kind == "ab":
         # ---- BASELINE configs[3]: HuDiff-Nb on abnativ_select_vhh, plain mask, 256 rows, same protocol -- a secondary object ----
@@ -544,7 +550,14 @@ def main():
             "value": round(value, 4), "unit": "sequences/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 via fp16 (hi, lo) split, 3 fp16 MFMAs per product (HUDIFF_X3=1 exported)" if x3_exported else "f32",
+            "dtype": "f32 via fp16 (hi, lo) split, 3 fp16 MFMAs per product (HUDIFF_X3=1 exported)" if x3_exported else
+                     "f32",
+            "dtype_detail": ("every kernel fp32 MFMA" if prec_main["split_built"] == 0 else
+                             "HUDIFF_X3=1: GEMMs and attention as three fp16 MFMAs per fp32 product on fp16 (hi, lo) operand splits, fp32 accumulation"
+                             if x3_exported else
+                             "GEMMs (Q|K|V, out-projection, FF, ByteNet taps: 90.5 % of the FLOPs): fp32 MFMA v_mfma_f32_32x32x2_f32; attention core "
+                             "(QK^T, PV: 9.5 % of the FLOPs): three fp16 MFMAs per product on fp16 (hi, lo) splits of the fp32 Q / K / V / P, fp32 "
+                             "accumulation and softmax (attn_x3_k; HUDIFF_ATTN_X3=0 -> attn_k, see all_fp32_kernels); range guard -> fp32 kernels"),
             "data": (("HuAb348 mouse pairs" if kind == "ab" else "abnativ_select_vhh VHH") +
                      f" ({batch['n_sequences']} sequences of the reference's evaluation CSV, IMGT-slotted by hudiff_amd.numbering into "
                      "hudiff_amd/data/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
@@ -570,6 +583,8 @@ def main():
             if split is not None:
                 attach_pmc(split["roofline"], live_pmc(args, kind, mode, x3=True))
                 phase("PMC passes (split precision)")
+        if all_fp32 is not None:
+            out["all_fp32_kernels"] = all_fp32
         if split is not None:
             out["split_precision"] = split
         if secondary is not None:

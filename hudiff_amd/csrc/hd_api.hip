@@ -117,7 +117,7 @@ struct HdModel {
     // them (weights whose residual stream leaves the fp16 range do so at every step): x3_suspended, counted in range_fallbacks.
     bool x3_suspended = false;
     int64_t range_fallbacks = 0;
-    bool attn_x3 = false;                            // HUDIFF_ATTN_X3=1 at hd_finalize: split-precision attention kernel inside the fp32 path
+    bool attn_x3 = true;                             // split-precision attention core (attn_x3_k) inside the fp32 path: the default since round 3; HUDIFF_ATTN_X3=0 at hd_finalize keeps attn_k
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
     std::vector<AttBlockW> att;
@@ -502,7 +502,11 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     Packer pk;
     X3Packer xpk;
     { const char* e = getenv("HUDIFF_X3"); m->x3 = e && atoi(e) != 0; }
-    { const char* e = getenv("HUDIFF_ATTN_X3"); m->attn_x3 = e && atoi(e) == 1; }
+    // Attention core of launches >= 8192 activation rows: attn_x3_k (S = K Q^T and O = V^T P^T as three fp16 MFMAs per product on
+    // fp16 (hi, lo) splits of the fp32 Q, K, V, P; fp32 accumulation, fp32 softmax, fp32 Q|K|V in, fp32 O out) unless HUDIFF_ATTN_X3=0.
+    // Round 2 measured it at 253 vs 483 us per launch with logits 1e-6 from attn_k's and identical tokens; round 3 put the range
+    // guard, the adversarial-statistics vectors and the whole GPU suite behind it (DESIGN.md sections 8, 9).
+    { const char* e = getenv("HUDIFF_ATTN_X3"); m->attn_x3 = !(e && atoi(e) == 0); }
     X3Packer* xp = m->x3 ? &xpk : nullptr;
     // HUDIFF_X3_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
     const int x3_mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 3; }();
@@ -1054,8 +1058,8 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
     // attn_x3_k<KT> masks only its last key tile: 16 (KT - 1) < L <= 16 KT (291 and 152 qualify); other lengths keep attn_k
     // ... and address QKV with 32-bit byte offsets
-    // HUDIFF_ATTN_X3=1 (read at hd_finalize): the split-precision attention kernel inside the fp32 path as well (fp32 Q|K|V in, fp32 O out); an
-    // experiment for the record, off by default: the product path computes in fp32 throughout
+    // m->attn_x3 (default; HUDIFF_ATTN_X3=0 at hd_finalize turns it off): the split-precision attention kernel inside the fp32 path as
+    // well (fp32 Q|K|V in, fp32 O out)
     const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;

@@ -17,8 +17,8 @@ for kind in KINDS:
     for variant in VARIANTS:
         z, cfg, sd = load_adv(kind, variant)
         st = dict(zip([str(n) for n in z["stat_names"]], z["stats"].tolist()))
-        for path in ("f32", "x3"):
-            m = _model(hudiff_amd, kind, cfg, sd, x3=(path == "x3"))
+        for path in ("f32_all", "f32", "x3"):
+            m = _model(hudiff_amd, kind, cfg, sd, x3=(path == "x3"), attn_x3=(path != "f32_all"))
             B = 32 if kind == "ab" else 56
             fill, tokens, region, chain = _big_batch(kind, z, B)
             lg = m(tokens, region, chain, dropout="off")

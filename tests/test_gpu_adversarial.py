@@ -21,18 +21,18 @@ def hip():
     return hudiff_amd
 
 
-def _model(hip, kind, cfg, sd, x3):
+def _model(hip, kind, cfg, sd, x3, attn_x3=True):
+    """x3: the split-precision GEMM kernels too (HUDIFF_X3=1); attn_x3=False: HUDIFF_ATTN_X3=0, i.e. every kernel fp32."""
     cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
-    prev = os.environ.get("HUDIFF_X3")
+    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
     os.environ["HUDIFF_X3"] = "1" if x3 else "0"
+    os.environ["HUDIFF_ATTN_X3"] = "1" if attn_x3 else "0"
     try:
         m = cls(**cfg)
         m.load_state_dict(sd)
     finally:
-        if prev is None:
-            os.environ.pop("HUDIFF_X3", None)
-        else:
-            os.environ["HUDIFF_X3"] = prev
+        for k, v in prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     return m
 
 
@@ -49,25 +49,26 @@ def _big_batch(kind, z, B):
     return fill, tokens, region, chain
 
 
-@pytest.mark.parametrize("path", ["f32", "x3"])
+@pytest.mark.parametrize("path", ["f32_all", "f32", "x3"])
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("kind", KINDS)
 def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
     z, cfg, sd = load_adv(kind, variant)
-    m = _model(hip, kind, cfg, sd, x3=(path == "x3"))
+    # f32_all: every kernel fp32; f32: the default product path (fp32 GEMMs + split-precision attention core); x3: HUDIFF_X3=1
+    m = _model(hip, kind, cfg, sd, x3=(path == "x3"), attn_x3=(path != "f32_all"))
     try:
         B = 32 if kind == "ab" else 56                       # 9 312 / 8 512 activation rows: the 128-row-tile kernels
         fill, tokens, region, chain = _big_batch(kind, z, B)
         logits = m(tokens, region, chain, dropout="off")
         assert np.isfinite(logits).all()
         info = m.precision_info()
-        if path == "x3":
+        if path == "f32_all":
+            assert info == {"split_built": 0, "split_in_use": False, "range_fallbacks": 0}
+        else:
             # |x| ~ 1e6 cannot be written as fp16 (hi, lo): the range guard must have repeated the forward on the fp32 kernels
             # (and only there: the other variants stay on the split-precision kernels)
-            assert info["split_built"] & 1
+            assert info["split_built"] == (3 if path == "x3" else 2)
             assert info["range_fallbacks"] == (1 if variant == "huge" else 0) and info["split_in_use"] == (variant != "huge")
-        else:
-            assert info == {"split_built": 0, "split_in_use": False, "range_fallbacks": 0}
         e32 = float(np.abs(logits[:2] - z["logits"]).max())
         e64 = float(np.abs(logits[:2] - z["logits_f64"]).max())
         assert e32 < LOGIT_TOL and e64 < LOGIT_TOL, (kind, variant, path, e32, e64, float(z["reference_f32_vs_f64"]))
@@ -95,14 +96,14 @@ def test_range_guard_inside_a_sampling_session(hip, kind):
     kernels with the same noise, so the tokens equal those of a handle that never had the split-precision kernels."""
     z, cfg, sd = load_adv(kind, "huge")
     cfg = dict(cfg, dropout=0.5 if kind == "nb" else 0.2)          # generated dropout: must be re-drawn identically in the re-run
-    mx, m32 = _model(hip, kind, cfg, sd, x3=True), _model(hip, kind, cfg, sd, x3=False)
+    mx, m32 = _model(hip, kind, cfg, sd, x3=True), _model(hip, kind, cfg, sd, x3=False, attn_x3=False)
     try:
         B = 72 if kind == "ab" else 120                              # two lanes, each >= 8192 activation rows
         fill, tokens, region, chain = _big_batch(kind, z, B)
         T = np.minimum(fill["T"], 5)
         args = (tokens, region, chain, fill["order"], T)
         got = mx.sample(*args, seed=21, row0=7)
-        assert mx.precision_info() == {"split_built": 1, "split_in_use": False, "range_fallbacks": 1}
+        assert mx.precision_info() == {"split_built": 3, "split_in_use": False, "range_fallbacks": 1}
         want = m32.sample(*args, seed=21, row0=7)
         assert np.array_equal(got, want)
         again = mx.sample(*args, seed=21, row0=7)                    # stays on the fp32 kernels: no second fallback

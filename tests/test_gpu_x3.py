@@ -28,17 +28,17 @@ def _pair(hip, kind, seed):
     cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
     sd = S.random_state_dict(kind, cfg, seed=seed)
     cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
-    prev = os.environ.get("HUDIFF_X3")
+    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
     try:
         os.environ["HUDIFF_X3"] = "0"
+        os.environ["HUDIFF_ATTN_X3"] = "0"               # m32: every kernel fp32 (attn_k)
         m32 = cls(**cfg); m32.load_state_dict(sd)
         os.environ["HUDIFF_X3"] = "1"
+        os.environ.pop("HUDIFF_ATTN_X3", None)
         mx3 = cls(**cfg); mx3.load_state_dict(sd)
     finally:
-        if prev is None:
-            os.environ.pop("HUDIFF_X3", None)
-        else:
-            os.environ["HUDIFF_X3"] = prev
+        for k, v in prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     return cfg, sd, m32, mx3
 
 
@@ -176,8 +176,9 @@ def test_x3_feature_masked_epilogues_change_nothing(hip, tmp_path):
 
 @pytest.mark.parametrize("kind", ["ab", "nb"])
 def test_split_attention_kernel_inside_the_fp32_path(hip, kind):
-    """HUDIFF_ATTN_X3=1 at hd_finalize: fp32 GEMMs with attn_x3_k in place of attn_k (fp32 Q|K|V in, fp32 O out).  Logits within
-    1e-4 of the all-fp32 kernels' (observed ~1e-6) and the same tokens on complete short samples."""
+    """The default product path since round 3: fp32 GEMMs with attn_x3_k in place of attn_k for launches >= 8192 rows (fp32 Q|K|V
+    in, fp32 O out); HUDIFF_ATTN_X3=0 at hd_finalize keeps attn_k.  Logits within 1e-4 of the all-fp32 kernels' (observed ~1e-6)
+    and the same tokens on complete short samples."""
     from hudiff_amd import evalsets as E
     from hudiff_amd import synthetic as S
     cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
@@ -186,10 +187,12 @@ def test_split_attention_kernel_inside_the_fp32_path(hip, kind):
     prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
     try:
         os.environ["HUDIFF_X3"] = "0"
-        os.environ.pop("HUDIFF_ATTN_X3", None)
+        os.environ["HUDIFF_ATTN_X3"] = "0"
         m32 = cls(**cfg); m32.load_state_dict(sd)
-        os.environ["HUDIFF_ATTN_X3"] = "1"
+        assert m32.precision_info()["split_built"] == 0
+        os.environ.pop("HUDIFF_ATTN_X3", None)             # the default
         mat = cls(**cfg); mat.load_state_dict(sd)
+        assert mat.precision_info() == {"split_built": 2, "split_in_use": True, "range_fallbacks": 0}
     finally:
         for k, v in prev.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
@@ -236,7 +239,7 @@ def test_x3_stress_200_forwards_two_lanes(hip, kind):
             again = mx3(batch["tokens"][:64], batch["region"][:64], np.concatenate([batch["chain"][:64], batch["chain"][B:B + 64]]), **kw) \
                 if kind == "ab" else mx3(batch["tokens"], batch["region"], None, **kw)
             assert np.array_equal(again, lg)
-        assert mx3.precision_info() == {"split_built": 1, "split_in_use": True, "range_fallbacks": 0}
+        assert mx3.precision_info() == {"split_built": 3, "split_in_use": True, "range_fallbacks": 0}
     finally:
         m32.close(); mx3.close()
 
