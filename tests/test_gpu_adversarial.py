@@ -68,7 +68,10 @@ def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
             # |x| ~ 1e6 cannot be written as fp16 (hi, lo): the range guard must have repeated the forward on the fp32 kernels
             # (and only there: the other variants stay on the split-precision kernels)
             assert info["split_built"] == (3 if path == "x3" else 2)
-            assert info["range_fallbacks"] == (1 if variant == "huge" else 0) and info["split_in_use"] == (variant != "huge")
+            # (the default path splits only Q / K / V / P inside the attention core, and the recipe keeps those O(1) even in the
+            # `huge` variant -- its guard is exercised by test_attention_core_range_guard below)
+            tripped = 1 if (variant == "huge" and path == "x3") else 0
+            assert info["range_fallbacks"] == tripped and info["split_in_use"] == (not tripped)
         e32 = float(np.abs(logits[:2] - z["logits"]).max())
         e64 = float(np.abs(logits[:2] - z["logits_f64"]).max())
         assert e32 < LOGIT_TOL and e64 < LOGIT_TOL, (kind, variant, path, e32, e64, float(z["reference_f32_vs_f64"]))
@@ -119,3 +122,27 @@ def test_range_guard_inside_a_sampling_session(hip, kind):
             mx2.close()
     finally:
         mx.close(); m32.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_attention_core_range_guard(hip, kind):
+    """The default product path (fp32 GEMMs + attn_x3_k): value projections scaled until |V| passes the fp16 range.  The split of
+    V in the attention kernel's staging must raise the range flag, the forward is repeated with attn_k, and the result equals the
+    all-fp32 handle's bit for bit (same kernels after the fallback)."""
+    z, cfg, sd = load_adv(kind, "massive")
+    sd = dict(sd)
+    for k in list(sd):
+        if k.endswith("attn_hl.value.weight") or k.endswith("attn_hl.value.bias"):
+            sd[k] = (sd[k] * np.float32(3.0e4)).astype(np.float32)
+        if k.endswith("attn_hl.out_put.weight"):
+            sd[k] = (sd[k] / np.float32(3.0e4)).astype(np.float32)
+    m, m32 = _model(hip, kind, cfg, sd, x3=False), _model(hip, kind, cfg, sd, x3=False, attn_x3=False)
+    try:
+        B = 32 if kind == "ab" else 56
+        fill, tokens, region, chain = _big_batch(kind, z, B)
+        a = m(tokens, region, chain, dropout="off")
+        assert m.precision_info() == {"split_built": 2, "split_in_use": False, "range_fallbacks": 1}
+        b = m32(tokens, region, chain, dropout="off")
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    finally:
+        m.close(); m32.close()
