@@ -263,8 +263,8 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 // four separate statements with no padding; it happened to work until an unrelated edit (the range guard in attn_x3_k) let the
 // scheduler place an MFMA one instruction behind the last v_fma_mixhi: every row of HuDiff-Ab came out 2e-2 wrong, silently
 // (found by bisecting with -DHD_SPLIT4_MODE, round 3).  Now: the two registers interleaved (lo, lo, hi, hi), early-clobber
-// outputs, `s_nop 1` closing the string.  Inputs must not come straight from a transcendental instruction (v_exp / v_rcp: one
-// wait state hipcc would not insert either); no caller does that.
+// outputs, `s_nop 1` closing the string and `s_nop 0` opening it (an input that comes straight from a transcendental instruction
+// -- v_exp for the softmax probabilities -- needs one wait state hipcc would not insert either).
 // HD_SPLIT4_MODE=1 builds the compiler-visible form instead (A/B aid).
 #ifndef HD_SPLIT4_MODE
 #define HD_SPLIT4_MODE 0
@@ -279,7 +279,8 @@ __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll
 #else
     const u32x2_t h = __builtin_bit_cast(u32x2_t, hh);
     unsigned int l0, l1;
-    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+    asm("s_nop 0\n\t"
+        "v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
         "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
         "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
