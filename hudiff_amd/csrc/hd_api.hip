@@ -1014,16 +1014,24 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     const LnApply ap{w.ln2_g, w.ln2_b, dh, act};
     launch_gemm(m, p, false, true, STATS_NONE, &ap);
 
+    // HUDIFF_PFF3_APPLY=1 (A/B aid, VERDICT r2 "Next" #8): h2 <- act(LN(h2)) in place by ln_apply_k as well, so that the last
+    // projection runs without its LayerNorm + activation prologue (recomputed per N tile otherwise).  Measured again in round 3
+    // (DESIGN.md section 8): the extra HBM pass still costs more than the prologue -- off.
+    static const bool pff3_apply = [] { const char* e = getenv("HUDIFF_PFF3_APPLY"); return e && atoi(e) == 1; }();
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    launch_gemm(m, p, true, true, STATS_PARTIALS);
+    const LnApply ap3f{w.ln3_g, w.ln3_b, dh, act};
+    if (pff3_apply) launch_gemm(m, p, true, true, STATS_NONE, &ap3f);
+    else launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
-    p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
-    use_partials(m, p);
+    if (!pff3_apply) {
+        p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+        use_partials(m, p);
+    }
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     p.C2 = out_split;
     set_drop(p, dr);
