@@ -293,6 +293,7 @@ def roofline_object(raw, T, flops_row, flops_row_exec, peak, unit, split):
         out["peak_note"] = ("fp32-equivalent peak of the split route: dense fp16 MFMA peak of the guide (2500 TFLOP/s at 2.4 GHz) / 3 "
                             "MFMAs per product")
     elif split == "default":
+        out["frac_vs_fp32_matrix_peak_157.3"] = round(tf / PEAK_F32_MATRIX_TFLOPS, 4)
         out["peak_note"] = ("GEMMs priced at the fp32 MFMA peak (157.3), the attention core (its share of the algorithmic FLOPs) at the "
                             "fp32-equivalent fp16 peak 2500 / 3: time-weighted harmonic mean; against 157.3 alone the fraction would be "
                             f"{tf / PEAK_F32_MATRIX_TFLOPS:.4f}")
