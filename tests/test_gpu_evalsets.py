@@ -206,3 +206,32 @@ def test_two_ranks_share_the_gpu(hip, tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["process_group"]["world_size"] == 2 and line["config"]["global_rows"] == 48
     assert line["all_tokens_valid"]
+
+
+@pytest.mark.parametrize("cfgno", [2, 4])
+def test_global_batches_of_the_multi_gpu_configs_are_shard_invariant(hip, cfgno):
+    """BASELINE configs[2] (HuDiff-Ab, 2048 HuAb348 rows on 8 GPUs) and configs[4] (HuDiff-Nb inpaint mask, 1024 VHH rows on 4 GPUs)
+    at their FULL global size on the one GPU there is: the same global rows sampled (three denoiser steps each, generated dropout)
+    as 8 (resp. 4) shards of 256 rows keyed by their global row ids -- what the ranks of a node do -- as shards of another size, and as
+    ONE launch of all rows must give identical tokens: the property that makes the multi-GPU job a pure concatenation."""
+    from hudiff_amd import evalsets as E
+    from hudiff_amd import synthetic as S
+    kind, dataset, mode, G = ("ab", "huab348", "finetune", 2048) if cfgno == 2 else ("nb", "vhh", "inpaint", 1024)
+    cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
+    m = (hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet)(**cfg)
+    m.load_state_dict(S.random_state_dict(kind, cfg, seed=4))
+    try:
+        full = E.eval_batch(dataset, G, mode=mode, row0=0)
+        T = np.minimum(full["T"], 3)
+
+        def run(lo, hi):
+            ch = None if full["chain"] is None else np.concatenate([full["chain"][lo:hi], full["chain"][G + lo:G + hi]])
+            return m.sample(full["tokens"][lo:hi], full["region"][lo:hi], ch, full["order"][lo:hi, :3], T[lo:hi], seed=17, row0=lo)
+        whole = run(0, G)
+        by256 = np.concatenate([run(lo, lo + 256) for lo in range(0, G, 256)])
+        by384 = np.concatenate([run(lo, min(lo + 384, G)) for lo in range(0, G, 384)])
+        assert np.array_equal(whole, by256) and np.array_equal(whole, by384)
+        changed = whole != full["tokens"]
+        assert (changed.sum(1) == T).all() and ((whole[changed] >= 0) & (whole[changed] <= 21)).all()
+    finally:
+        m.close()
