@@ -1048,6 +1048,13 @@ static bool att_x3(const HdModel* m, const Segs& sg) {
     return x3_use(m, sg, w.a1.wqkvx) && x3_use(m, sg, w.a1.wox) && x3_use(m, sg, w.a2.wqkvx) && x3_use(m, sg, w.a2.wox) &&
            x3_use(m, sg, w.wf1x) && x3_use(m, sg, w.wf2x) && cur(m).ws.YX && cur(m).ws.ATX;
 }
+// HUDIFF_LDS_NO_PAD=1 (diagnostic, scripts/lds_fill_probe.py): dynamic LDS requests are NOT padded by the co-residency rule, so
+// that the exact-fill geometry of round 2 (two 81 920-byte blocks on a CU) can be reproduced on demand
+static size_t lds_request(int bytes, int threads) {
+    static const bool no_pad = [] { const char* e = getenv("HUDIFF_LDS_NO_PAD"); return e && atoi(e) == 1; }();
+    return (size_t)(no_pad ? bytes : lds_safe_request(bytes, threads));
+}
+
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
                             const float* resid, float* out, bool want_out_stats, bool x3 = false,
                             const float* x_split = nullptr, float* out_split = nullptr) {
@@ -1060,7 +1067,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     launch_gemm(m, p, false, false);
     // dynamic LDS requests obey the co-residency rule (hd_kernels.hip.h): a request whose co-resident blocks would fill the
     // CU's 160 KB is padded until one block fewer fits
-    const size_t smem = (size_t)lds_safe_request((int)((size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float)), ATT_THREADS);
+    const size_t smem = lds_request((int)((size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float)), ATT_THREADS);
     dim3 grid(sg.B * m->cfg.nhead);
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
     static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
@@ -1072,9 +1079,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
-        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), (size_t)lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
+        hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), lds_request(AxGeom<19>::SMEM, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
-        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), (size_t)lds_safe_request(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
+        hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), lds_request(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     } else if (m->L > 160)
         hipLaunchKernelGGL(attn_k<19>, grid, dim3(ATT_THREADS), smem, st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, x3 ? 1 : 0, rsp);
     else

@@ -260,3 +260,38 @@ def test_whole_gpu_suite_with_split_precision_as_process_default(tmp_path):
     tail = r.stdout[-1500:]
     assert r.returncode == 0, tail + r.stderr[-1500:]
     assert " passed" in tail and " failed" not in tail, tail
+
+
+@pytest.mark.parametrize("L", [152, 160])
+def test_attention_blocks_that_would_fill_the_lds_exactly(hip, L):
+    """ADVICE r2 / DESIGN section 5 "LDS co-residency rule": at L = 160 the nanobody attention kernels would take 81 920 B per block --
+    two co-resident blocks = the CU's 163 840 B exactly, the geometry that produced wrong rows in round 2.  The launch now pads such
+    a request until one block fewer fits (lds_safe_request); L = 152 keeps two blocks per CU with 4 KB to spare.  Both lengths: the
+    split-precision route against the all-fp32 route, and 12 repeated forwards bit-identical."""
+    from hudiff_amd import synthetic as S
+    cfg = dict(S.NB_CONFIG, max_len=L)
+    sd = S.random_state_dict("nb", cfg, seed=6)
+    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
+    try:
+        os.environ["HUDIFF_X3"], os.environ["HUDIFF_ATTN_X3"] = "0", "0"
+        m32 = hip.NanoAntiTFNet(**cfg); m32.load_state_dict(sd)
+        os.environ["HUDIFF_X3"] = "1"
+        os.environ.pop("HUDIFF_ATTN_X3", None)
+        mx3 = hip.NanoAntiTFNet(**cfg); mx3.load_state_dict(sd)
+    finally:
+        for k, v in prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    try:
+        B = 128                                              # >= 8192 activation rows, 1 024 attention blocks
+        rng = np.random.default_rng(L)
+        tokens = rng.integers(0, 23, size=(B, L)).astype(np.int32)
+        region = rng.integers(0, 7, size=(B, L)).astype(np.int32)
+        kw = dict(dropout="faithful", seed=5, row0=0, step=3)
+        ref = m32(tokens, region, None, **kw)
+        first = mx3(tokens, region, None, **kw)
+        assert np.abs(first - ref).max() < LOGIT_TOL
+        for _ in range(11):
+            assert np.array_equal(mx3(tokens, region, None, **kw), first)
+        assert mx3.precision_info()["range_fallbacks"] == 0
+    finally:
+        m32.close(); mx3.close()
