@@ -12,7 +12,13 @@
 //                 SGPR descriptors, immediate-offset LDS reads): on gfx950 VALU and MFMA time-slice one issue port.
 //   attn_k        RoPE + softmax(QK^T/8) V for one (row, head): K/V staged in LDS, S^T = K Q^T kept in
 //                 MFMA accumulators (16x16x4 f32) so the softmax is lane-local and P feeds PV directly
-//                 (model/encoder/cross_attention.py:149-173)
+//                 (model/encoder/cross_attention.py:149-173); small launches and the all-fp32 route
+//   attn_x3_k     the same structure with every product as three fp16 MFMAs on fp16 (hi, lo) operand splits (fp32 accumulation and
+//                 softmax, fp32 in / out): the attention core of the DEFAULT route for launches >= 8192 rows since round 3
+//   gemm_x3_k     split-precision GEMM (HUDIFF_X3=1): operands as fp16 (hi, lo) planes by LDS DMA, three MFMAs per product; its
+//                 ByteNet launches normalise their own output rows (ln_sync: the N tiles of an M tile meet at an L2-level counter)
+//   guards        every producer of an fp16 split checks |x| < 65504 (RunState::pad[1] -> the host repeats the call on fp32 kernels);
+//                 co-resident blocks never fill a CU's LDS to the last 2 KB (lds_fill_ok / lds_safe_request)
 //   row_stats_k   per-row (mean, rstd) for LayerNorm, one wave per row, two-pass
 //   small kernels token gather, region/position/side embedding, final LN+decoder+exponential-race
 //                 sampling (antibody_scripts/sample.py:510-513), full decoder for hd_forward
