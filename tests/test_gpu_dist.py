@@ -92,3 +92,34 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["process_group"]["world_size"] == 2 and line["config"]["global_rows"] == 48
     assert line["all_tokens_valid"] and line["scaling"] == "weak"
+
+
+def test_default_bench_line_carries_the_measurement_contract(tmp_path):
+    """One default-shaped `python bench.py` run (smaller batch, bounded CPU leg): the single JSON line must hold everything the
+    measurement contract names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config.workload; `roofline`
+    with bound, achieved, peak, frac, traffic (live PMC), hbm_gbps and mfma_busy; `cpu_baseline` with value / cores / kind / sample; the
+    all-fp32 and split-precision lines with their own rooflines; the HuDiff-Nb secondary line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "1", "--warmup", "0",
+                        "--cpu-rows", "2", "--cpu-steps", "2"], env=_clean_env(), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                      # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "sequences/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "HuAb348" in d["metric"] and "workload" in d["config"] and d["config"]["rows_per_gpu"] == 64
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"].startswith("TFLOP/s") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] and roof["traffic"] > 1e9 and roof["hbm_gbps"] > 100 and 0.05 < roof["mfma_busy"] < 1.0
+    assert roof["route"] == "default" and 157.3 < roof["peak"] < 175 and "frac_vs_fp32_matrix_peak_157.3" in roof
+    assert d["precision_info"] == {"split_built": 2, "split_in_use": True, "range_fallbacks": 0}
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "sequences/s" and cpu["sample"]
+    a, s = d["all_fp32_kernels"], d["split_precision"]
+    assert a["roofline"]["peak"] == 157.3 and a["precision_info"]["split_built"] == 0
+    assert abs(s["roofline"]["peak"] - 2500 / 3) < 0.01 and s["roofline"]["traffic"] and s["precision_info"]["split_built"] == 3
+    assert s["max_abs_dlogit_vs_f32_path"] < 1e-4 and s["rows_with_identical_tokens"].startswith("64 of 64")
+    nb = d["secondary"]["hudiff_nb_configs3"]
+    assert nb["f32"]["value"] > 0 and nb["split_precision"]["value"] > 0 and "configs[3]" in nb["config"]["workload"]
+    assert d["all_tokens_valid"]
