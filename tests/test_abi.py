@@ -101,3 +101,30 @@ def test_flops_formula_matches_survey():
     c.max_len, c.d_model, c.sum_d_model, c.att_model, c.dim_feedforward, c.kernel_size = 291, 256, 768, 512, 256, 7
     c.n_encoder_layers, c.dual_layers, c.cs_layers, c.n_tokens = 6, 6, 5, 23
     assert abs(lib.hd_flops_per_row_forward(C.byref(c)) - 18.336296448e9) < 1
+
+
+def test_bench_route_peaks_follow_the_library_flop_formula():
+    """bench.py prices the default route against a time-weighted peak built from the attention core's share of the algorithmic
+    FLOPs; that share must come out of the same formula the library exports (hd_flops_per_row_forward)."""
+    import ctypes as C
+    import importlib.util
+    from hudiff_amd import _lib as L
+    from hudiff_amd import synthetic as S
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib = L.load()
+    for kind, cfg, want_total in (("ab", S.AB_CONFIG, 18.336e9), ("nb", S.NB_CONFIG, 5.707e9)):
+        c = L.HdConfig()
+        c.abi_version, c.kind = L.HD_ABI_VERSION, (0 if kind == "ab" else 1)
+        c.n_tokens, c.max_len, c.d_model, c.sum_d_model = cfg["n_tokens"], cfg["max_len"], cfg["d_model"], cfg["sum_d_model"]
+        c.n_encoder_layers, c.dual_layers, c.kernel_size = cfg["n_encoder_layers"], cfg["dual_layers"], cfg["aa_kernel_size"]
+        c.att_model, c.nhead, c.dim_feedforward, c.cs_layers = cfg["att_model"], cfg["nhead"], cfg["dim_feedforward"], cfg["cs_layers"]
+        total = float(lib.hd_flops_per_row_forward(C.byref(c)))
+        assert abs(total - want_total) / want_total < 1e-3
+        core = 2.0 * cfg["cs_layers"] * 4 * cfg["max_len"] * cfg["att_model"] * cfg["max_len"]
+        share = bench.attention_core_share(cfg)
+        assert abs(share - core / total) < 1e-9
+        pk = bench.route_peak(cfg, "default")
+        assert bench.route_peak(cfg, "all_fp32") == 157.3 and abs(bench.route_peak(cfg, "split") - 2500 / 3) < 1e-9
+        assert abs(1.0 / pk - ((1 - share) / 157.3 + share / (2500 / 3))) < 1e-12 and 157.3 < pk < 175
