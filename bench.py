@@ -318,6 +318,11 @@ def live_pmc(args, kind, mode, x3, n_steps=4):
     tmp = tempfile.mkdtemp(prefix="hudiff_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", HUDIFF_X3="1" if x3 else "0")
     env.pop("HUDIFF_ATTN_X3", None)
+    # the profiled run is a single-rank job on this rank's GPU, also when this process is one rank of N (launcher variables scrubbed)
+    for k in list(env):
+        if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                 "HUDIFF_BENCH_FORCE_PG", "HUDIFF_BENCH_SHARE_GPU", "HUDIFF_DIST_FORCE") or k.startswith("TORCHELASTIC_"):
+            env.pop(k)
     try:
         for n, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
             out = os.path.join(tmp, f"pass{n}")
@@ -608,8 +613,13 @@ def main():
             "precision_info": prec_main,
         }
         # HBM-side traffic, HBM GB/s and MFMA-busy per launch: live PMC passes of this very command (subprocess, after the timed region)
-        if args.pmc in ("auto", "live") and not only_main:
+        # (N > 1: rank 0 profiles a single-rank run of the same per-GPU workload on its own GPU while the other ranks wait at the
+        #  final barrier -- the ranks are independent, so its counters are every rank's)
+        pmc_wanted = args.pmc in ("auto", "live") and not args.only_main and args.max_t <= 0 and (not force_pg or world > 1)
+        if pmc_wanted and (not only_main or world > 1):
             attach_pmc(out["roofline"], live_pmc(args, kind, mode, x3=x3_exported))
+            if world > 1 and "pmc_note" in out["roofline"]:
+                out["roofline"]["pmc_note"] += f"; taken on rank 0's GPU (single-rank run of the per-GPU workload), N = {world}"
             phase("PMC passes (f32)")
             if split is not None:
                 attach_pmc(split["roofline"], live_pmc(args, kind, mode, x3=True))

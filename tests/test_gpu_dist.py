@@ -94,6 +94,20 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     assert line["all_tokens_valid"] and line["scaling"] == "weak"
 
 
+def test_bench_gpus_2_reports_rank_0_counters(tmp_path):
+    """N > 1 lines carry HBM traffic / GB/s / MFMA-busy too (north_star: "rocprof-reported HBM GB/s and MFMA utilisation ... at
+    1/2/4/8 GPUs"): rank 0 profiles a single-rank run of the per-GPU workload while the other rank waits at the final barrier."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "24",
+                        "--no-cpu-baseline"], env=_clean_env(HUDIFF_BENCH_SHARE_GPU="1"), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    roof = line["roofline"]
+    assert line["n_gpus"] == 2 and line["config"]["global_rows"] == 48 and line["all_tokens_valid"]
+    assert roof["traffic"] and roof["traffic"] > 1e8 and roof["hbm_gbps"] > 10 and 0.0 < roof["mfma_busy"] < 1.0
+    assert "rank 0" in roof["pmc_note"] and "N = 2" in roof["pmc_note"]
+    assert "split_precision" not in line and "cpu_baseline" not in line          # N > 1: the metric's own leg only
+
+
 def test_default_bench_line_carries_the_measurement_contract(tmp_path):
     """One default-shaped `python bench.py` run (smaller batch, bounded CPU leg): the single JSON line must hold everything the
     measurement contract names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config.workload; `roofline`
