@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over the attention core of the default route (counters only + kernel trace): scripts/attn_pmc.sh OUTNAME [ENV=VAL ...]
+# PMC passes over selected kernels of the default route (counters only + kernel trace): scripts/attn_pmc.sh OUTNAME [ENV=VAL ...]
+# PMC_FILTER=regex selects the kernels (default: the attention core)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$1; shift
@@ -13,11 +14,11 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE
       python $R/bench.py --steps 1 --warmup 0 --max-t 2 --no-cpu-baseline --lanes 1 --no-graph --pmc off --only-main > $OUT/p$i.log 2>&1
 done
 python3 - <<PY > $OUT/attn_pmc.txt
-import csv, glob, collections, re
+import csv, glob, collections, re, os
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "attn_x3_k" not in r["Kernel_Name"] and "attn_k" not in r["Kernel_Name"]:
+        if not re.search(os.environ.get("PMC_FILTER", "attn_x3_k|attn_k<"), r["Kernel_Name"]):
             continue
         k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0] + " g=" + r["Grid_Size"]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
