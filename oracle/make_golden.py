@@ -309,6 +309,32 @@ def main():
                 loc=loc.astype(np.int64), q=np.stack(rec.q), step_logits=np.stack([s[1] for s in steps]),
                 step_probs=np.stack([s[2] for s in steps]), step_sampled=np.stack([s[3] for s in steps]), final=final)
 
+        # ---- antibody INPAINT mask (`--sample_method inpaint`, sample.py:283-310, 486-489): the inputs are what the reference's own
+        #      batch_inpaint_input_element built for a CDR-grafted HuAb348 pair (tests/golden/input_prep.json, written by
+        #      oracle/make_golden_inputs.py from that function: framework positions that differ from the graft template masked, the
+        #      grafted CDRs kept); the reference loop then samples them.  Own generator, as above.
+        if kind == "ab":
+            import json
+            with open(os.path.join(OUT, "input_prep.json")) as f:
+                case = next(c for c in json.load(f)["cases"] if c["name"] == "huab348_7")
+            e = case["expect"]["inpaint_pad0"]
+            Bg = 3
+            tokens = np.repeat(np.array(e["tokens"], np.int64)[None], Bg, 0)
+            region = np.repeat(np.array(e["region"], np.int64)[None], Bg, 0)
+            chain = np.array([e["chain"][0]] * Bg + [e["chain"][-1]] * Bg, np.int64)
+            loc = np.array(e["loc"], np.int64)
+            assert (tokens[0, loc] == 22).all() and (tokens[0] == 22).sum() == len(loc) == 62
+            np.random.seed(2025)
+            np.random.shuffle(loc)
+            torch.manual_seed(2025)
+            with Recorder() as rec:
+                final, steps = ref_sample_loop(model0, tokens, region, chain, loc, rec)
+            assert not rec.masks
+            np.savez_compressed(
+                os.path.join(OUT, "micro_ab_sample_graft.npz"), tokens=tokens, region=region, chain=chain,
+                loc=loc.astype(np.int64), q=np.stack(rec.q), step_logits=np.stack([s[1] for s in steps]),
+                step_probs=np.stack([s[2] for s in steps]), step_sampled=np.stack([s[3] for s in steps]), final=final)
+
         np.savez_compressed(os.path.join(OUT, f"micro_{kind}_config.npz"),
                             **{k: np.array(v) for k, v in cfg0.items()})
         print(kind, "golden written; params:", sum(v.size for v in sd.values()))

@@ -68,10 +68,10 @@ def test_forward_generated_dropout_matches_oracle_contract(micro):
     assert np.abs(logits - want).max() < LOGIT_TOL
 
 
-@pytest.mark.parametrize("mode", ["finetune", "pretrain", "plain", "inpaint"])
+@pytest.mark.parametrize("mode", ["finetune", "pretrain", "graft", "plain", "inpaint"])
 @pytest.mark.parametrize("graph", [True, False, "loop"])
 def test_full_sampling_trace_bit_exact(micro, mode, graph):
-    if (micro["kind"] == "ab") != (mode in ("finetune", "pretrain")):        # pretrain: sample.py:148-151, T = 185
+    if (micro["kind"] == "ab") != (mode in ("finetune", "pretrain", "graft")):        # pretrain: sample.py:148-151, T = 185; graft: `--sample_method inpaint` inputs (sample.py:283-310) built by the reference for a HuAb348 pair
         pytest.skip("mode belongs to the other model")
     z = load_golden(f"micro_{micro['kind']}_sample_{mode}.npz")
     B, loc = z["tokens"].shape[0], z["loc"]
