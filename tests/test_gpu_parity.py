@@ -419,3 +419,36 @@ def test_large_batch_properties(hip):
             assert set(np.nonzero(changed[b])[0]) == set(visited.tolist())
     finally:
         m.close()
+
+
+def test_two_handles_driven_by_two_host_threads(hip):
+    """Boundary contract (SURVEY.md 8b "Threading"): a handle is not re-entrant, but separate handles may be driven by separate host
+    threads.  An antibody and a nanobody handle sample concurrently (ctypes releases the GIL inside the library) and must give what
+    they give one after the other."""
+    import threading
+    from hudiff_amd import synthetic as S
+    jobs = {}
+    for kind in ("ab", "nb"):
+        cfg, sd = load_cfg(kind), load_weights(kind)
+        m = _mk(hip, kind, dict(cfg, dropout=0.3), sd)
+        b = S.synthetic_batch(kind, 70, seed=5 if kind == "ab" else 6)
+        jobs[kind] = (m, b, dict(seed=99, row0=3, dropout="faithful"))
+    run = lambda kind: jobs[kind][0].sample(jobs[kind][1]["tokens"], jobs[kind][1]["region"], jobs[kind][1]["chain"], jobs[kind][1]["order"],
+                                            np.minimum(jobs[kind][1]["T"], 12), **jobs[kind][2])
+    serial = {k: run(k) for k in jobs}
+    for rep in range(3):
+        got, errs = {}, []
+
+        def work(kind):
+            try:
+                got[kind] = run(kind)
+            except Exception as e:          # surfaced below: an exception inside a thread would otherwise pass silently
+                errs.append((kind, e))
+        ts = [threading.Thread(target=work, args=(k,)) for k in jobs]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for k in jobs:
+            assert np.array_equal(got[k], serial[k]), (k, rep)
+    for k in jobs:
+        jobs[k][0].close()
