@@ -1264,6 +1264,11 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 // split-precision kernels (whole path or attention only) currently in use / switched off for good by the range guard
 static bool split_active(const HdModel* m) { return (m->x3 || m->attn_x3) && !m->x3_suspended; }
 static void suspend_split(HdModel* m) {
+    // said once per handle (stderr; HUDIFF_QUIET=1 silences it): from here on the handle runs the all-fp32 kernels, at their speed
+    static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();
+    if (!m->x3_suspended && !quiet)
+        fprintf(stderr, "[hudiff_hip] an activation left the fp16 range (|x| >= 65504): this call is repeated on the fp32 kernels and the handle "
+                        "stays on them (hd_precision_info.range_fallbacks)\n");
     m->x3_suspended = true;
     m->range_fallbacks += 1;
     for (auto& ln : m->lane) ln.drop_graphs();      // captured with the split kernels
