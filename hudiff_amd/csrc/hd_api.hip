@@ -683,6 +683,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     if (L > 160) HIP_TRY(hipFuncSetAttribute((const void*)attn_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     else HIP_TRY(hipFuncSetAttribute((const void*)attn_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19, AX19_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     static_assert(lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS) <= LDS_PER_CU && lds_safe_request(AxGeom<10>::SMEM, ATT_THREADS) <= LDS_PER_CU, "LDS co-residency rule");
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
@@ -1078,7 +1079,10 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
-    if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
+    static const bool ax_w8 = [] { const char* e = getenv("HUDIFF_ATTN_WAVES"); return e && atoi(e) == 8; }();
+    if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19 && !ax_w8)
+        hipLaunchKernelGGL((attn_x3_k<19, AX19_THREADS>), grid, dim3(AX19_THREADS), lds_request(AxGeom<19>::SMEM, AX19_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
+    else if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
         hipLaunchKernelGGL(attn_x3_k<19>, grid, dim3(ATT_THREADS), lds_request(AxGeom<19>::SMEM, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     else if (ax_ok && m->L > 16 * 9 && m->L <= 16 * 10) {
         hipLaunchKernelGGL(attn_x3_k<10>, grid, dim3(ATT_THREADS), lds_request(2 * 128 * m->L + 2 * AxGeom<10>::VPLANE, ATT_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
@@ -1336,7 +1340,7 @@ static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, 
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = ln.ws;
     // the injected Exp(1) noise lives once, for the whole batch, in the model (m->qnoise)
-    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
+    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64 * SS_WAVES), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
                        ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0);
     hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
     HIP_TRY(hipGetLastError());

@@ -1675,9 +1675,12 @@ template <int KT> struct AxGeom {
     }
 };
 constexpr int AX_KROWS = AxGeom<19>::KROWS;        // longest sequence the kernel family covers
+constexpr int AX19_THREADS = 768;                  // block size of attn_x3_k<19> (HUDIFF_ATTN_WAVES=8 launches the 512-thread instantiation)
 
-template <int KT>
-__global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
+// NTH: threads per block.  KT = 19 runs twelve waves (three per SIMD, 160 VGPRs): the tile loop's MFMA, LDS and vector-ALU phases of
+// three waves interleave better than those of two (227.9 -> 217.7 us per launch); KT = 10 keeps eight (two blocks per CU).
+template <int KT, int NTH = ATT_THREADS>
+__global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
                                                             const float* __restrict__ rope_cos,
                                                             const float* __restrict__ rope_sin,
                                                             float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split,
@@ -1716,9 +1719,9 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
     //      value is consumed: one exposed round trip per block instead of two.
     {
         float vmax = 0.f;                              // range guard: K and V are split from fp32 values here (X16_LIMIT)
-        constexpr int NST = (AX_KROWS * 16 + ATT_THREADS - 1) / ATT_THREADS;
+        constexpr int NST = (AX_KROWS * 16 + NTH - 1) / NTH;
         constexpr int NCHUNK = AX_VKEYS / 8;                          // 40 / 20 chunks of 8 keys
-        constexpr int NCH = (NCHUNK + ATT_THREADS / 64 - 1) / (ATT_THREADS / 64);
+        constexpr int NCH = (NCHUNK + NTH / 64 - 1) / (NTH / 64);
         f32x4 kb[NST];
         float2 cb[NST], sb[NST];
         float vv[NCH][8];
@@ -1727,7 +1730,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         const int kcol = (koff + (tid & 15) * 4) * 4, rcol = (tid & 15) * 8;              // byte offsets inside a row
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int key = min((tid >> 4) + (ATT_THREADS / 16) * k, L - 1);
+            const int key = min((tid >> 4) + (NTH / 16) * k, L - 1);
             const int row = key + (key >= roff1 ? rA1 : rA0);
             kb[k] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(q_rs, (int)((uint32_t)row * rowb + (uint32_t)kcol), 0, 0));
             cb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(c_rs, key * 128 + rcol, 0, 0));
@@ -1735,7 +1738,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         }
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) {
-            const int c = min(wave + (ATT_THREADS / 64) * cc, NCHUNK - 1);            // chunk 4 t + g (wave-uniform)
+            const int c = min(wave + (NTH / 64) * cc, NCHUNK - 1);            // chunk 4 t + g (wave-uniform)
             const int t = c >> 2, g = c & 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1746,7 +1749,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         }
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int idx = tid + ATT_THREADS * k;
+            const int idx = tid + NTH * k;
             if (idx < krows * 16) {
                 const int key = idx >> 4, c4 = (idx & 15) * 4;
                 const f32x4 kv = kb[k];
@@ -1764,7 +1767,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         }
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) {
-            const int c = wave + (ATT_THREADS / 64) * cc;
+            const int c = wave + (NTH / 64) * cc;
             if (c >= NCHUNK) continue;
             const int t = c >> 2, g = c & 3;
             f16x8 hh, ll;
@@ -1805,7 +1808,7 @@ __global__ void __launch_bounds__(ATT_THREADS, KT <= 10 ? 4 : 1) attn_x3_k(const
         vph[par] = Vh + qi * (AX_VKEYS * 2) + (G::vpos(4 * par + g, qi) << 4);
         vpl[par] = vph[par] + AX_VPLANE;
     }
-    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
+    for (int qt = wave; qt < nqt; qt += NTH / 64) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
         const long qrow = sg.row(b, qc);
@@ -2144,27 +2147,38 @@ __device__ __forceinline__ void ln_row_regs(const float* __restrict__ x, int D, 
     }
 }
 
-__global__ void __launch_bounds__(64) sample_step_k(const float* __restrict__ Hm, int D, HeadW w,
+// Four waves per sequence: each normalises the row (the same arithmetic, so the same values) and takes the decoder rows
+// j = wave, wave + 4, ...; wave 0 then runs the softmax and the draw on the 22 logits (one wave per sequence with 22 serial
+// dot products was 103 us of latency per step).
+constexpr int SS_WAVES = 4;
+__global__ void __launch_bounds__(64 * SS_WAVES) sample_step_k(const float* __restrict__ Hm, int D, HeadW w,
                                                      int32_t* __restrict__ tokens,
                                                      const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ T, int Tmax,
                                                      const float* __restrict__ q_noise, int q_rows, int q_off,
                                                      const RunState* __restrict__ rs, Segs sg, int compact) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ float lg[32];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = rs->step;
     if ((int)t >= T[b]) return;
     const int slot = order[(long)b * Tmax + t];
     float y[16];
     // compact: Hm is [B, D] holding only the visited row of each sequence (pruned last block)
     ln_row_regs(Hm + (compact ? (long)b : (long)sg.row(b, slot)) * D, D, lane, w, y);
-    float mylogit = -INFINITY;
-    for (int j = 0; j < 22; ++j) {
-        float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; if (c < D) a += y[i] * w.w[(long)j * D + c]; }
-        a = wave_sum(a) + w.b[j];
-        if (lane == j) mylogit = a;
+    for (int jj = 0; jj < (22 + SS_WAVES - 1) / SS_WAVES; ++jj) {
+        const int j = wave + SS_WAVES * jj;
+        if (j < 22) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { int c = lane + 64 * i; if (c < D) a += y[i] * w.w[(long)j * D + c]; }
+            a = wave_sum(a) + w.b[j];
+            if (lane == 0) lg[j] = a;
+        }
     }
+    __syncthreads();
+    if (wave != 0) return;
+    const float mylogit = lane < 22 ? lg[lane] : -INFINITY;
     const float mx = wave_max(mylogit);
     const float e = (lane < 22) ? expf(mylogit - mx) : 0.f;
     const float esum = wave_sum(e);

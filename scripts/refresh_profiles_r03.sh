@@ -26,6 +26,18 @@ prof ab256_allfp32 ab HUDIFF_X3=0 HUDIFF_ATTN_X3=0
 prof ab256_x3 ab HUDIFF_X3=1
 prof nb256 nb HUDIFF_X3=0
 prof nb256_x3 nb HUDIFF_X3=1
+# dispatch sequence of one denoiser step + per-launch roofline budget (scripts/launch_budget.py) on the three routes
+seq() {   # name, route, env...
+  name=$1; route=$2; shift 2
+  CMD="python $R/bench.py --steps 1 --warmup 0 --max-t 4 --no-cpu-baseline --lanes 1 --pmc off --only-main"
+  env "$@" timeout 400 rocprofv3 --kernel-trace -d $OUT/sq_$name -o t -- $CMD > $OUT/sq_$name.log 2>&1
+  python $R/scripts/rocpd_summary.py $(find $OUT/sq_$name -name "*.db" | head -1) --sequence > $OUT/${name}_step_sequence.txt
+  python $R/scripts/launch_budget.py $OUT/${name}_step_sequence.txt $route > $OUT/${name}_launch_budget.txt
+  rm -rf $OUT/sq_$name $OUT/sq_$name.log
+}
+seq ab256 default HUDIFF_X3=0
+seq ab256_allfp32 allfp32 HUDIFF_X3=0 HUDIFF_ATTN_X3=0
+seq ab256_x3 x3 HUDIFF_X3=1
 python $R/scripts/adv_report.py $OUT/adversarial_errors.json > $OUT/adv.log 2>&1
 bash $R/scripts/x3_ab.sh HUDIFF_X3_LNSYNC "0 2" 1 > $OUT/lnsync_ab.txt 2>&1
 echo "$HEAD" > $OUT/GIT_HEAD
