@@ -623,6 +623,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
 // (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
 __device__ __forceinline__ float2 merge_row_stat(const float2* __restrict__ spart, int spw, long spart_rows, int Kc, long grow) {
     const int P = (Kc + spw - 1) / spw;
+    constexpr int PM = 16;
+    if (P <= PM) {
+        // all slices of the row in flight at once, both passes from registers: ONE round trip (the partials were written by the
+        // previous launch) instead of two; the same additions in the same order as the loops below
+        float2 u[PM];
+#pragma unroll
+        for (int s = 0; s < PM; ++s)
+            if (s < P) u[s] = spart[(long)s * spart_rows + grow];
+        float mean = 0.f;
+#pragma unroll
+        for (int s = 0; s < PM; ++s)
+            if (s < P) mean += u[s].x * (float)min(spw, Kc - s * spw);
+        mean /= (float)Kc;
+        float m2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < PM; ++s)
+            if (s < P) {
+                const float d = u[s].x - mean;
+                m2 += u[s].y + (float)min(spw, Kc - s * spw) * d * d;
+            }
+        return make_float2(mean, 1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+    }
     float mean = 0.f;
     for (int s = 0; s < P; ++s) mean += spart[(long)s * spart_rows + grow].x * (float)min(spw, Kc - s * spw);
     mean /= (float)Kc;
