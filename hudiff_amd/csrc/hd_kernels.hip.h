@@ -2043,23 +2043,15 @@ __global__ void __launch_bounds__(256) attn_row_k(const float* __restrict__ Qc, 
     sum = wave_sum(sum);
     if (Pw) {
         const float inv = 1.0f / sum;
-        const int P = (Kc + spw - 1) / spw;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int key = lane + 64 * i;
             if (key < L) {
                 const long row = sg.row(b, key);
-                float mean = 0.f;               // Chan merge of the row's (mean, M2) slice partials -> rstd
-                for (int s2 = 0; s2 < P; ++s2) mean += spart[(long)s2 * spart_rows + row].x * (float)min(spw, Kc - s2 * spw);
-                mean /= (float)Kc;
-                float m2 = 0.f;
-                for (int s2 = 0; s2 < P; ++s2) {
-                    const float2 pr = spart[(long)s2 * spart_rows + row];
-                    const float d = pr.x - mean;
-                    m2 += pr.y + (float)min(spw, Kc - s2 * spw) * d * d;
-                }
+                // Chan merge of the row's (mean, M2) slice partials -> rstd (merge_row_stat: all slices in flight at once)
+                const float rstd = merge_row_stat(spart, spw, spart_rows, Kc, row).y;
                 const float e = __builtin_amdgcn_exp2f(sc[i] - mx);
-                Pw[(long)bh * 320 + key] = e * inv * (1.0f / sqrtf(m2 / (float)Kc + 1e-5f));
+                Pw[(long)bh * 320 + key] = e * inv * rstd;
             }
         }
         return;
@@ -2133,6 +2125,20 @@ __global__ void __launch_bounds__(256) head_proj_k(const float* __restrict__ Y, 
     const float* wp = Wv + h * ATT_HD + d;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int c = 0;
+    // sixteen weight loads in flight per step (the loop is bound by their round trips); every accumulator still receives its
+    // terms c = k (mod 4) in increasing c, i.e. the additions and their order are those of the plain loop below
+    for (; c + 15 < D; c += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = wp[(long)(c + u) * ldw];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            a0 = __builtin_fmaf(yh[c + u], wv[u], a0);
+            a1 = __builtin_fmaf(yh[c + u + 1], wv[u + 1], a1);
+            a2 = __builtin_fmaf(yh[c + u + 2], wv[u + 2], a2);
+            a3 = __builtin_fmaf(yh[c + u + 3], wv[u + 3], a3);
+        }
+    }
     for (; c + 3 < D; c += 4) {
         a0 = __builtin_fmaf(yh[c], wp[(long)c * ldw], a0);
         a1 = __builtin_fmaf(yh[c + 1], wp[(long)(c + 1) * ldw], a1);
