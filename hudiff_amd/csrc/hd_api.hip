@@ -960,8 +960,10 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
                           float* out_split = nullptr, const ByteNetW* next = nullptr) {
     const int rows = sg.rows();
     const int ks = m->cfg.kernel_size;
-    if (x_stats == X_NONE) launch_stats(m, x, ldx, din, rows, cur(m).stream);
-    if (x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && x3_use(m, sg, w.w3x) && cur(m).ws.S1) {
+    const bool x3_route = x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && x3_use(m, sg, w.w3x) && cur(m).ws.S1;
+    // (the split-precision route's ln_apply_k computes the statistics of a row it holds anyway: no separate pass)
+    if (x_stats == X_NONE && !(x3_route && din <= 1024)) launch_stats(m, x, ldx, din, rows, cur(m).stream);
+    if (x3_route) {
         // Split-precision route.  Every GEMM operand is act(LN(.)) of the previous result in split (hi, lo) form and the three
         // projections run on gemm_x3_k without a prologue.  (The fp32 route recomputes LayerNorm + activation in every N tile's
         // prologue, which costs more than the MFMAs once those are three fp16 instructions.)  Who writes the operand:
@@ -974,9 +976,9 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
         const int seg1 = sg.nseg > 1 ? sg.base[1] : rows;
         const bool sync = x3_lnsync() && ws.SYNC;
         if (x_stats != X_S1) {
-            const bool from_part = x_stats == X_PARTIALS;
+            const bool from_part = x_stats == X_PARTIALS, self = x_stats == X_NONE && din <= 1024;
             hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
-                               ws.part_last_pw, din, rows, x, ldx, ws.S1, din, from_part ? (const float2*)nullptr : (const float2*)ws.ST,
+                               ws.part_last_pw, din, rows, x, ldx, ws.S1, din, (from_part || self) ? (const float2*)nullptr : (const float2*)ws.ST,
                                w.ln1_g, w.ln1_b, din, seg1, act, 1, (const RunState*)cur(m).rs);
         }
         GemmP p = base_gemm(m, sg);

@@ -1255,9 +1255,25 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
     if (stats) {
         const float2 st = stats[row];
         mean = st.x; rstd = st.y;
-    } else {
+    } else if (part) {
         const float2 st = merge_row_stat(part, pw, rows, C, row);
         mean = st.x; rstd = st.y;
+    } else {
+        // neither: the statistics of the row this wave already holds (split_out only), with row_stats_k's own arithmetic -- the
+        // same sums in the same order -- so that a separate statistics pass over the tensor is not needed
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane * 4 + 256 * j < C) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane * 4 + 256 * j < C) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = v[j][k] - mean; q += d * d; }
+            }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
     }
     const int seg = row >= seg1_row0 ? 1 : 0;
     const float* g = gamma + seg * k_stride;
