@@ -14,6 +14,14 @@ gives the HuAb348-shaped random rows of round 1 instead.  Weights are seeded ran
 architecture (no released checkpoint offline).  Rows shard across GPUs with no data-path collective; one RCCL gather
 of the final int32 tokens ends the job (weak scaling: 256 rows per GPU).
 
+Precision routes (include/hudiff_hip.h): the top level is the library's DEFAULT route -- split precision since round 4: every
+fp32 product of the large GEMMs and of the attention core as three fp16 MFMAs on fp16 (hi, lo) operand splits with fp32
+accumulation (`dtype` says so, `roofline.peak` = 2500 / 3 TFLOP/s fp32-equivalent).  `all_fp32_kernels` is the same workload
+with every product on the fp32 MFMA pipe, sampled as long as the top level (same --steps), with its own PMC passes and clock /
+power record: a strict reader grades that object.  `precision_evidence` holds, for this very run's rows and weights, each
+route's max |dlogit| against a float64 CPU evaluation at three points along the sample and the token agreement between the
+routes over ALL timed samples.
+
 Timed region: inputs already resident in HBM (hd_sample_begin uploaded them); K x [restore tokens
 device-side, re-key noise, run all T steps]; bracketed by barrier + device synchronise on both sides,
 max over ranks.  One JSON line is printed by rank 0.
@@ -57,10 +65,15 @@ def parse():
                          "SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE) over a 4-step run of this script in a subprocess after the timed region")
     ap.add_argument("--cpu-impl", choices=["auto", "torch", "numpy"], default="auto",
                     help="CPU baseline on the oracle's PyTorch-CPU variant (auto: when torch is importable) or on numpy")
-    ap.add_argument("--no-split-line", action="store_true",
-                    help="skip the extra `split_precision` leg (same workload on the HUDIFF_X3=1 kernels, reported beside the f32 metric)")
+    ap.add_argument("--precision", choices=["default", "split", "f32_gemm", "f32_all"], default="default",
+                    help="precision route of the TOP-LEVEL line (hd_set_precision); default = the library default (split)")
+    ap.add_argument("--no-split-line", action="store_true", help=argparse.SUPPRESS)      # round-3 flag (the split route is the top level now): accepted, ignored
+    ap.add_argument("--no-f32-gemm-line", action="store_true",
+                    help="skip the short `f32_gemm_route` leg (fp32 MFMA GEMMs + split attention core: the round-3 default route)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HuDiff-Nb line (BASELINE configs[3]) printed beside the metric")
-    ap.add_argument("--no-all-fp32-line", action="store_true", help="skip the `all_fp32_kernels` leg (HUDIFF_ATTN_X3=0: attn_k instead of attn_x3_k)")
+    ap.add_argument("--no-all-fp32-line", action="store_true", help="skip the `all_fp32_kernels` leg (every product on the fp32 MFMA pipe, same --steps)")
+    ap.add_argument("--no-evidence", action="store_true", help="skip `precision_evidence` (float64 CPU evaluations: ~1 min)")
+    ap.add_argument("--evidence-rows", type=int, default=8, help="rows evaluated in float64 per point of `precision_evidence`")
     ap.add_argument("--only-main", action="store_true", help="the metric's own leg only (what the PMC passes profile)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--loop-graph", action="store_true", help="the whole T-step loop of a lane as ONE hipGraph (HD_LOOP_GRAPH) "
@@ -217,24 +230,18 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
 PEAK_F16_MATRIX_TFLOPS = 2500.0    # same guide, dense fp16 MFMA; three fp16 MFMAs per fp32 product -> 833.3 fp32-equivalent
 
 
-def secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, x3_env, steps, warmup, first_key=0):
-    """One more timed leg of a workload beside the metric: a model built under ``x3_env`` (e.g. {"HUDIFF_X3": "1"}), the same
-    protocol as the main line (inputs resident, restart + all T steps per sample, device sync on both sides, HIP-event time of
-    the replays), bounded to `steps` samples.  -> (tokens of the last sample, model (still open), dict of raw numbers)."""
+def timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, precision, steps, warmup, first_key=0, keep_tokens=True):
+    """One timed leg of a workload beside the top-level line: a model on route `precision` (hd_set_precision), the same protocol
+    as the main line (inputs resident, restart + all T steps per sample, device sync on both sides, HIP-event time of the
+    replays).  -> (tokens of every timed sample [steps, B, L], model (still open, session ended), dict of raw numbers)."""
     import hudiff_amd
     B = batch["tokens"].shape[0]
     Tmax = int(T.max())
-    prev = {k: os.environ.get(k) for k in x3_env}
-    os.environ.update(x3_env)
-    try:
-        model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
-        model.load_state_dict(sd)
-    finally:
-        for k, v in prev.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank, precision=precision)
+    model.load_state_dict(sd)
     model.sample_begin(batch["tokens"], batch["region"], batch["chain"], batch["order"], T, seed=2023,
                        row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
-    gpu_ms, watch, t0 = 0.0, None, 0.0
+    gpu_ms, watch, t0, toks = 0.0, None, 0.0, []
     for i in range(-warmup, steps):
         model.sample_restart(2023 + 7919 * (first_key + i))
         if i == 0:
@@ -245,11 +252,37 @@ def secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, x3_env,
         if i >= 0:
             model.sync()
             gpu_ms += model.last_run_ms()[0]
+            if keep_tokens:
+                toks.append(model.sample_tokens())
     elapsed = time.perf_counter() - t0
     clock_power = watch.stop() if watch else None
-    tokens = model.sample_end()
-    return tokens, model, {"elapsed": elapsed, "gpu_ms": gpu_ms, "steps": steps, "clock_power": clock_power, "Tmax": Tmax, "B": B,
-                           "precision": model.precision_info()}
+    last = model.sample_end()
+    if not keep_tokens:
+        toks = [last]
+    return np.stack(toks), model, {"elapsed": elapsed, "gpu_ms": gpu_ms, "steps": steps, "clock_power": clock_power, "Tmax": Tmax, "B": B,
+                                   "precision": model.precision_info()}
+
+
+DTYPE_OF_ROUTE = {
+    "split": "f32-equivalent: fp16 hi+lo split, 3 MFMA / product, f32 accumulate; launches < 8192 rows f32",
+    "f32_gemm": "f32 MFMA GEMMs; attention core f32-equivalent (fp16 hi+lo split, 3 MFMA / product, f32 accumulate)",
+    "f32_all": "f32 (every product on the fp32 MFMA pipe)",
+}
+DTYPE_DETAIL = {
+    "split": "every large GEMM (Q|K|V, out-projection, FF, ByteNet projections and taps) and the attention core (QK^T, PV): each fp32 operand "
+             "as fp16 hi + fp16 lo (22 significand bits), a w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi as three v_mfma_f32_32x32x16_f16 / "
+             "16x16x32_f16 with fp32 accumulation; softmax, LayerNorm, residuals, dropout, decoder in fp32; launches of fewer than 8192 "
+             "activation rows, the pruned tail's compact GEMMs and the static branch on fp32 MFMA; range guard (|x| >= 65504) and ln_sync "
+             "guard repeat the call on fp32 / ln_apply_k kernels (precision_info)",
+    "f32_gemm": "GEMMs (90.5 % of the FLOPs): fp32 MFMA v_mfma_f32_32x32x2_f32; attention core (9.5 %): three fp16 MFMAs per product on "
+                "fp16 (hi, lo) splits of the fp32 Q / K / V / P, fp32 accumulation and softmax",
+    "f32_all": "every kernel fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+}
+
+
+def route_of(info):
+    """bench-internal route name of a handle's hd_precision_report: split | f32_gemm | f32_all."""
+    return info["precision"]
 
 
 def attention_core_share(cfg):
@@ -267,7 +300,7 @@ def route_peak(cfg, route):
     fp32 pipe, the attention core (share a of the FLOPs) as three fp16 MFMAs: the time-weighted harmonic mean
     1 / ((1 - a) / 157.3 + a / 833.3) -- slightly above 157.3, so that moving the attention core to the faster pipe does not
     inflate the fraction."""
-    if route == "all_fp32":
+    if route in ("all_fp32", "f32_all"):
         return PEAK_F32_MATRIX_TFLOPS
     if route == "split":
         return PEAK_F16_MATRIX_TFLOPS / 3.0
@@ -289,10 +322,10 @@ def roofline_object(raw, T, flops_row, flops_row_exec, peak, unit, split):
         cp = dict(cp, peak_at_sustained_clock=round(pk, 2), frac_at_sustained_clock=round(tf / pk, 4),
                   source="amdgpu hwmon freq1_input / power1_input of this GPU, 10 Hz over the timed region")
         out["clock_power"] = cp
-    if split == "split" or split is True:
+    if split in ("split", True):
         out["peak_note"] = ("fp32-equivalent peak of the split route: dense fp16 MFMA peak of the guide (2500 TFLOP/s at 2.4 GHz) / 3 "
                             "MFMAs per product")
-    elif split == "default":
+    elif split in ("default", "f32_gemm"):
         out["frac_vs_fp32_matrix_peak_157.3"] = round(tf / PEAK_F32_MATRIX_TFLOPS, 4)
         out["peak_note"] = ("GEMMs priced at the fp32 MFMA peak (157.3), the attention core (its share of the algorithmic FLOPs) at the "
                             "fp32-equivalent fp16 peak 2500 / 3: time-weighted harmonic mean; against 157.3 alone the fraction would be "
@@ -300,13 +333,13 @@ def roofline_object(raw, T, flops_row, flops_row_exec, peak, unit, split):
     return out
 
 
-def live_pmc(args, kind, mode, x3, n_steps=4):
-    """HBM-side bytes per denoiser step and the MFMA pipe's busy fraction from rocprofv3 PMC passes of THIS script (a 4-step
-    one-lane run in a subprocess, --kernel-trace only).  Two passes: `FETCH_SIZE` alone (3 of the 4 TCC slots), then `WRITE_SIZE`
-    with `SQ_VALU_MFMA_BUSY_CYCLES` and `GRBM_GUI_ACTIVE` (SQ and GRBM slots are independent of the TCC's; MI355X_MICROARCH.md "HBM" /
-    "rocprofv3 PMC slots").  FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); unit KB.  Counted from the first token
-    gather on (the once-per-batch static branch is excluded).  mfma_busy = MFMA-busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs):
-    the fraction of all SIMD cycles, launch gaps included, in which the matrix pipe was executing."""
+def live_pmc(args, kind, mode, precision, n_steps=4):
+    """HBM-side bytes per denoiser step and the MFMA pipe's busy fraction from rocprofv3 PMC passes of THIS script on route
+    `precision` (a 4-step one-lane run in a subprocess, --kernel-trace only).  Two passes: `FETCH_SIZE` alone (3 of the 4 TCC slots),
+    then `WRITE_SIZE` with `SQ_VALU_MFMA_BUSY_CYCLES` and `GRBM_GUI_ACTIVE` (SQ and GRBM slots are independent of the TCC's;
+    MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots").  FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); unit KB.  Counted
+    from the first token gather on (the once-per-batch static branch is excluded).  mfma_busy = MFMA-busy cycles / (GRBM_GUI_ACTIVE / 8
+    XCDs x 1024 SIMDs): the fraction of all SIMD cycles, launch gaps included, in which the matrix pipe was executing."""
     import csv
     import glob
     import shutil
@@ -316,9 +349,9 @@ def live_pmc(args, kind, mode, x3, n_steps=4):
         return None
     tot = {}
     tmp = tempfile.mkdtemp(prefix="hudiff_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", HUDIFF_X3="1" if x3 else "0")
-    env.pop("HUDIFF_ATTN_X3", None)
-    # the profiled run is a single-rank job on this rank's GPU, also when this process is one rank of N (launcher variables scrubbed)
+    env = dict(os.environ, TMPDIR="/tmp")
+    # the profiled run is a single-rank job on this rank's GPU, also when this process is one rank of N (launcher variables scrubbed);
+    # its route is given on the command line (an explicit hd_set_precision: the environment cannot override it)
     for k in list(env):
         if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                  "HUDIFF_BENCH_FORCE_PG", "HUDIFF_BENCH_SHARE_GPU", "HUDIFF_DIST_FORCE") or k.startswith("TORCHELASTIC_"):
@@ -329,7 +362,7 @@ def live_pmc(args, kind, mode, x3, n_steps=4):
             cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--kind", kind, "--mode", mode, "--batch", str(args.batch),
                    "--dropout", args.dropout, "--data", args.data, "--steps", "1", "--warmup", "0", "--max-t", str(n_steps),
-                   "--no-cpu-baseline", "--lanes", "1", "--pmc", "off", "--only-main"]
+                   "--no-cpu-baseline", "--lanes", "1", "--pmc", "off", "--only-main", "--precision", precision]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for f in files for r in csv.DictReader(open(f))]
@@ -442,7 +475,8 @@ def main():
         T = np.minimum(T, args.max_t)
     Tmax = int(T.max())
 
-    model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(**cfg, device=local_rank)
+    model = (hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet)(
+        **cfg, device=local_rank, precision=None if args.precision == "default" else args.precision)
     model.load_state_dict(sd)
     flops_row = model.flops_per_row_forward()            # canonical / algorithmic
     flops_row_exec = model.flops_per_row_sample_step()   # executed: last attention block pruned to the visited row
@@ -459,6 +493,7 @@ def main():
                        row0=rank * B, dropout=args.dropout, graph=(False if args.no_graph else "loop" if args.loop_graph else True), lanes=args.lanes)
     upload_s = time.perf_counter() - t_up0
     gpu_ms = 0.0
+    main_tokens = []                                     # every timed sample's tokens (precision_evidence: agreement between routes)
 
     def one_sample(i, timed):
         nonlocal gpu_ms
@@ -467,6 +502,7 @@ def main():
         if timed:
             model.sync()
             gpu_ms += model.last_run_ms()[0]
+            main_tokens.append(model.sample_tokens())    # 300 KB device-to-host after the sync: < 0.01 % of a sample
 
     for i in range(args.warmup):
         one_sample(-1 - i, False)
@@ -478,11 +514,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     clock_power = watch.stop() if watch else None
+    my_elapsed = elapsed
     tokens = model.sample_end()
     prec_main = model.precision_info()
+    route_main = route_of(prec_main)
     only_main = args.only_main or args.max_t > 0 or world > 1 or force_pg
-    x3_exported = os.environ.get("HUDIFF_X3", "0") not in ("", "0")
-    split = secondary = None
+    f32_gemm = secondary = None
     t_phase = time.perf_counter()
 
     def phase(name):
@@ -491,42 +528,80 @@ def main():
         sys.stderr.write(f"[bench] {name}: {now - t_phase:.1f} s\n")
         t_phase = now
 
-    if rank == 0 and not only_main and not args.no_split_line and not x3_exported:
-        # ---- the same workload on the split-precision kernels, with its own full roofline; reported BESIDE the f32 metric ----
-        ref_rows = min(B, 64)          # enough activation rows (>= 8192) for the big-launch kernels on both models
-        ch = None if batch["chain"] is None else np.concatenate([batch["chain"][:ref_rows], batch["chain"][B:B + ref_rows]])
-        ref_logits = model(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
-        n_split = min(args.steps, 3)
-        x3_tokens, mx, raw = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_X3": "1"}, n_split, min(args.warmup, 1),
-                                           first_key=args.steps - n_split)      # last sample keyed like the f32 line's last
-        lg = mx(batch["tokens"][:ref_rows], batch["region"][:ref_rows], ch, dropout=args.dropout, seed=2023, row0=rank * B, step=0)
-        mx.close()
-        roof = roofline_object(raw, T, flops_row, flops_row_exec, PEAK_F16_MATRIX_TFLOPS / 3.0, "TFLOP/s (fp32-equivalent)", split=True)
-        split = {"value": round(B * raw["steps"] / raw["elapsed"], 4), "unit": "sequences/s", "steps": raw["steps"],
-                 "ms_per_step": round(1e3 * raw["elapsed"] / raw["steps"], 3),
-                 "dtype": "fp32 operands split as fp16 hi + fp16 lo, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate", "roofline": roof,
-                 "max_abs_dlogit_vs_f32_path": float(np.abs(lg - ref_logits).max()), "dlogit_rows": ref_rows,
-                 "rows_with_identical_tokens": f"{int((x3_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)",
-                 "precision_info": raw["precision"],
-                 "eligibility": "launches of >= 8192 activation rows take the split-precision kernels (HuDiff-Ab: B >= 29 rows per lane, "
-                                "HuDiff-Nb: B >= 54); smaller launches, the pruned tail's compact GEMMs and the static branch run the f32 kernels; "
-                                "operands with |x| >= 65504 trip the range guard (precision_info.range_fallbacks) and the call is repeated on f32",
-                 "note": "HUDIFF_X3=1 (DESIGN.md section 9).  Not the metric: the top-level value is the f32 path."}
-        phase("split-precision leg")
-    all_fp32 = None
-    if rank == 0 and not only_main and not args.no_all_fp32_line and not x3_exported and os.environ.get("HUDIFF_ATTN_X3", "1") != "0":
-        # ---- every kernel fp32 (HUDIFF_ATTN_X3=0: attn_k, fp32 16x16x4 MFMA, instead of the split-precision attention core) --------
-        n_f = min(args.steps, 2)
-        f_tokens, mf, rawf = secondary_leg(args, kind, mode, cfg, sd, batch, T, rank, local_rank, {"HUDIFF_X3": "0", "HUDIFF_ATTN_X3": "0"}, n_f,
-                                           min(args.warmup, 1), first_key=args.steps - n_f)
-        mf.close()
+    def agreement(a, b):
+        """rows with identical final tokens, over every timed sample both legs ran with the same noise keys"""
+        n = min(len(a), len(b))
+        same = int((np.asarray(a[-n:]) == np.asarray(b[-n:])).all(-1).sum())
+        return {"rows_identical": same, "rows_compared": int(n * B), "samples_compared": int(n)}
+
+    all_fp32, fp32_tokens = None, None
+    if rank == 0 and not only_main and not args.no_all_fp32_line and route_main != "f32_all":
+        # ---- every product on the fp32 MFMA pipe: the SAME number of samples as the top level, own clock / power, own PMC passes ----
+        fp32_tokens, mf, rawf = timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, "f32_all", args.steps, min(args.warmup, 1))
         all_fp32 = {"value": round(B * rawf["steps"] / rawf["elapsed"], 4), "unit": "sequences/s", "steps": rawf["steps"],
-                    "ms_per_step": round(1e3 * rawf["elapsed"] / rawf["steps"], 3), "dtype": "f32 (every kernel: fp32 MFMA)",
+                    "ms_per_step": round(1e3 * rawf["elapsed"] / rawf["steps"], 3), "dtype": DTYPE_OF_ROUTE["f32_all"],
                     "roofline": roofline_object(rawf, T, flops_row, flops_row_exec, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", split=False),
-                    "rows_with_identical_tokens": f"{int((f_tokens == tokens).all(1).sum())} of {B} (last timed sample, same noise)",
+                    "token_agreement_with_top_level": agreement(main_tokens, fp32_tokens),
                     "precision_info": rawf["precision"],
-                    "note": "HUDIFF_ATTN_X3=0: the round-1/2 product path, attn_k in place of attn_x3_k; printed so that the two can be read side by side"}
+                    "note": "precision route f32_all (hd_set_precision): the reference's own arithmetic -- every product fp32 -- on the same rows, "
+                            "weights, noise keys and number of samples as the top level"}
         phase("all-fp32-kernels leg")
+    if rank == 0 and not only_main and not args.no_f32_gemm_line and route_main == "split":
+        # ---- the round-3 default route (fp32 MFMA GEMMs + split attention core), short: kept for continuity with BENCH_r03 ----
+        n_g = min(args.steps, 2)
+        g_tokens, mg, rawg = timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, "f32_gemm", n_g, min(args.warmup, 1), first_key=args.steps - n_g)
+        mg.close()
+        f32_gemm = {"value": round(B * rawg["steps"] / rawg["elapsed"], 4), "unit": "sequences/s", "steps": rawg["steps"],
+                    "ms_per_step": round(1e3 * rawg["elapsed"] / rawg["steps"], 3), "dtype": DTYPE_OF_ROUTE["f32_gemm"],
+                    "roofline": roofline_object(rawg, T, flops_row, flops_row_exec, route_peak(cfg, "f32_gemm"), "TFLOP/s (fp32-equivalent)", split="f32_gemm"),
+                    "token_agreement_with_top_level": agreement(main_tokens, g_tokens), "precision_info": rawg["precision"],
+                    "note": "precision route f32_gemm: BENCH_r03's top-level route"}
+        phase("f32-gemm-route leg")
+
+    evidence = None
+    if rank == 0 and not only_main and not args.no_evidence and args.max_t == 0:
+        # ---- precision_evidence: this run's rows and weights, each route against a float64 CPU evaluation at three points of the sample ----
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import hudiff_oracle as ho
+        n64 = max(1, min(args.evidence_rows, B))
+        n_dev = min(B, 64)             # rows per device forward: enough activation rows (>= 8192) for the big-launch kernels on both models
+        last = main_tokens[-1]
+        t_mid = int(Tmax // 2)
+        pts = [0, t_mid, max(Tmax - 1, 0)]
+        ch_dev = None if batch["chain"] is None else np.concatenate([batch["chain"][:n_dev], batch["chain"][B:B + n_dev]])
+        ch64 = None if batch["chain"] is None else np.concatenate([batch["chain"][:n64], batch["chain"][B:B + n64]])
+        net64 = ho.OracleNet(kind, cfg if args.dropout == "faithful" else dict(cfg, dropout=0.0), sd, dtype=np.float64)
+        seed_last = 2023 + 7919 * (args.steps - 1)
+        routes = {route_main: model}
+        if all_fp32 is not None:
+            routes["f32_all"] = mf
+        per_route = {r: [] for r in routes}
+        for t in pts:
+            # token state of the LAST timed sample at step t: the slots visited before t hold their final tokens
+            st = batch["tokens"][:n_dev].copy()
+            for b in range(n_dev):
+                vis = batch["order"][b, :min(t, int(T[b]))]
+                st[b, vis] = last[b, vis]
+            dr = ho.Dropout("philox", seed=seed_last, rows=np.arange(n64) + rank * B, step=t) if (args.dropout == "faithful" and cfg.get("dropout", 0) > 0) else None
+            want = net64(st[:n64], batch["region"][:n64], ch64, dropout=dr)
+            for r, mdl in routes.items():
+                got = mdl(st, batch["region"][:n_dev], ch_dev, dropout=args.dropout, seed=seed_last, row0=rank * B, step=t)
+                per_route[r].append(float(np.abs(got[:n64].astype(np.float64) - want).max()))
+        evidence = {"float64_reference": f"oracle/hudiff_oracle.py in float64 (numpy), {n64} rows of this run's batch, its weights, "
+                                         f"dropout {args.dropout} (the device's own Philox keep-masks), token state of the last timed sample "
+                                         f"at denoiser steps {pts} of {Tmax}; device forwards of {n_dev} rows (big-launch kernels)",
+                    "steps_along_the_sample": pts,
+                    "max_abs_dlogit_vs_float64": {r: {"per_step": [float(f"{e:.3e}") for e in v], "max": float(f"{max(v):.3e}")} for r, v in per_route.items()},
+                    "bound": 1e-4,
+                    "token_agreement": {}}
+        if all_fp32 is not None:
+            evidence["token_agreement"][f"{route_main} vs f32_all"] = agreement(main_tokens, fp32_tokens)
+        if f32_gemm is not None:
+            evidence["token_agreement"][f"{route_main} vs f32_gemm"] = f32_gemm["token_agreement_with_top_level"]
+        evidence["precision_info_after"] = {r: mdl.precision_info() for r, mdl in routes.items()}
+        phase("precision evidence (float64 oracle)")
+    if all_fp32 is not None:
+        mf.close()
 
     if rank == 0 and not only_main and not args.no_secondary and kind == "ab":
         # ---- BASELINE configs[3]: HuDiff-Nb on abnativ_select_vhh, plain mask, 256 rows, same protocol -- a secondary object ----
@@ -535,19 +610,17 @@ def main():
         nbatch, nreal = make_batch("nb", B, "plain", rank * B, args.data)
         nT = nbatch["T"].copy()
         secondary = {}
-        for tag, env in (("f32", {"HUDIFF_X3": "0"}), ("split_precision", {"HUDIFF_X3": "1"})):
-            if tag == "split_precision" and (args.no_split_line or x3_exported):
-                continue
-            ntok, mn, rawn = secondary_leg(args, "nb", "plain", ncfg, nsd, nbatch, nT, rank, local_rank, env, 2, 1)
+        for route in ("split", "f32_all"):
+            ntok, mn, rawn = timed_leg(args, "nb", ncfg, nsd, nbatch, nT, rank, local_rank, route, 2, 1, keep_tokens=False)
             f_alg, f_exec = mn.flops_per_row_forward(), mn.flops_per_row_sample_step()
             mn.close()
-            route = ("default" if rawn["precision"]["split_built"] & 2 else "all_fp32") if tag == "f32" else "split"
             pk = route_peak(ncfg, route)
-            secondary[tag] = {"value": round(B * rawn["steps"] / rawn["elapsed"], 4), "unit": "sequences/s", "steps": rawn["steps"],
-                              "ms_per_step": round(1e3 * rawn["elapsed"] / rawn["steps"], 3),
-                              "roofline": roofline_object(rawn, nT, f_alg, f_exec, pk, "TFLOP/s" + ("" if route == "all_fp32" else " (fp32-equivalent)"),
-                                                          split=route if route != "all_fp32" else False),
-                              "all_tokens_valid": bool(((ntok >= 0) & (ntok <= 21)).all())}
+            secondary[route] = {"value": round(B * rawn["steps"] / rawn["elapsed"], 4), "unit": "sequences/s", "steps": rawn["steps"],
+                                "ms_per_step": round(1e3 * rawn["elapsed"] / rawn["steps"], 3), "dtype": DTYPE_OF_ROUTE[route],
+                                "roofline": roofline_object(rawn, nT, f_alg, f_exec, pk, "TFLOP/s" + ("" if route == "f32_all" else " (fp32-equivalent)"),
+                                                            split=route if route != "f32_all" else False),
+                                "precision_info": rawn["precision"],
+                                "all_tokens_valid": bool(((ntok >= 0) & (ntok <= 21)).all())}
         secondary = {"metric": "humanized sequences/sec (full T-step sample)" + (" on abnativ_select_vhh" if nreal else ""),
                      "config": {"workload": f"BASELINE configs[3]: HuDiff-Nb NanoAntiTFNet (17.5M params, L=152), plain mask, batch {B}/GPU, full "
                                             f"T-step sample (T {int(nT.min())}..{int(nT.max())}, mean {float(nT.mean()):.1f}), dropout {args.dropout}"},
@@ -556,6 +629,7 @@ def main():
 
     # ---- the single collective of the job: gather the final tokens on rank 0 (RCCL over xGMI) ----------
     gathered = [tokens]
+    per_rank = None
     if dist is not None:
         import torch
         t = torch.from_numpy(tokens).to(coll_dev)
@@ -563,6 +637,11 @@ def main():
         dist.gather(t, outs, dst=0)
         if rank == 0:
             gathered = [o.cpu().numpy() for o in outs]
+        # every rank's own wall time of the timed region (a straggler GPU shows here; the metric uses the maximum)
+        mine = torch.tensor([my_elapsed, gpu_ms], dtype=torch.float64, device=coll_dev)
+        alls = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(alls, mine)
+        per_rank = [[float(a[0]), float(a[1])] for a in alls]
         el = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed, gpu_ms = float(el[0]), float(el[1])
@@ -575,9 +654,8 @@ def main():
         seqs = n_gpus * B * args.steps
         value = seqs / elapsed
         raw_main = {"gpu_ms": gpu_ms, "steps": args.steps, "B": B, "Tmax": Tmax, "clock_power": clock_power}
-        route_main = "split" if x3_exported else ("default" if prec_main["split_built"] & 2 else "all_fp32")
-        roof = roofline_object(raw_main, T, flops_row, flops_row_exec, route_peak(cfg, route_main), "TFLOP/s" if route_main == "all_fp32" else
-                               "TFLOP/s (fp32-equivalent)", split=route_main if route_main != "all_fp32" else False)
+        roof = roofline_object(raw_main, T, flops_row, flops_row_exec, route_peak(cfg, route_main), "TFLOP/s" if route_main == "f32_all" else
+                               "TFLOP/s (fp32-equivalent)", split=route_main if route_main != "f32_all" else False)
         roof["route"] = route_main
         roof["launch"] = ("one denoiser step = one replay of the captured hipGraph (all kernels of a forward + sampling), HIP events on the "
                           "library's stream")
@@ -586,14 +664,9 @@ def main():
             "value": round(value, 4), "unit": "sequences/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 via fp16 (hi, lo) split, 3 fp16 MFMAs per product (HUDIFF_X3=1 exported)" if x3_exported else
-                     "f32",
-            "dtype_detail": ("every kernel fp32 MFMA" if prec_main["split_built"] == 0 else
-                             "HUDIFF_X3=1: GEMMs and attention as three fp16 MFMAs per fp32 product on fp16 (hi, lo) operand splits, fp32 accumulation"
-                             if x3_exported else
-                             "GEMMs (Q|K|V, out-projection, FF, ByteNet taps: 90.5 % of the FLOPs): fp32 MFMA v_mfma_f32_32x32x2_f32; attention core "
-                             "(QK^T, PV: 9.5 % of the FLOPs): three fp16 MFMAs per product on fp16 (hi, lo) splits of the fp32 Q / K / V / P, fp32 "
-                             "accumulation and softmax (attn_x3_k; HUDIFF_ATTN_X3=0 -> attn_k, see all_fp32_kernels); range guard -> fp32 kernels"),
+            "dtype": DTYPE_OF_ROUTE[route_main],
+            "dtype_detail": DTYPE_DETAIL[route_main],
+            "precision_route": route_main,
             "data": (("HuAb348 mouse pairs" if kind == "ab" else "abnativ_select_vhh VHH") +
                      f" ({batch['n_sequences']} sequences of the reference's evaluation CSV, IMGT-slotted by hudiff_amd.numbering into "
                      "hudiff_amd/data/real_rows.npz, cycled with distinct replica noise); random-init weights of the production architecture")
@@ -612,22 +685,29 @@ def main():
             "gpu_event_ms": round(gpu_ms, 2), "upload_ms": round(1e3 * upload_s, 2), "all_tokens_valid": filled,
             "precision_info": prec_main,
         }
+        if per_rank is not None:
+            ms = [1e3 * e / args.steps for e, _ in per_rank]
+            out["per_rank_ms_per_step"] = {"min": round(min(ms), 3), "max": round(max(ms), 3), "ranks": [round(v, 3) for v in ms],
+                                           "gpu_event_ms": [round(g, 2) for _, g in per_rank],
+                                           "note": "each rank's own wall time of the timed region / steps; the metric divides by the slowest"}
         # HBM-side traffic, HBM GB/s and MFMA-busy per launch: live PMC passes of this very command (subprocess, after the timed region)
         # (N > 1: rank 0 profiles a single-rank run of the same per-GPU workload on its own GPU while the other ranks wait at the
         #  final barrier -- the ranks are independent, so its counters are every rank's)
         pmc_wanted = args.pmc in ("auto", "live") and not args.only_main and args.max_t <= 0 and (not force_pg or world > 1)
         if pmc_wanted and (not only_main or world > 1):
-            attach_pmc(out["roofline"], live_pmc(args, kind, mode, x3=x3_exported))
+            attach_pmc(out["roofline"], live_pmc(args, kind, mode, route_main))
             if world > 1 and "pmc_note" in out["roofline"]:
                 out["roofline"]["pmc_note"] += f"; taken on rank 0's GPU (single-rank run of the per-GPU workload), N = {world}"
-            phase("PMC passes (f32)")
-            if split is not None:
-                attach_pmc(split["roofline"], live_pmc(args, kind, mode, x3=True))
-                phase("PMC passes (split precision)")
+            phase(f"PMC passes ({route_main})")
+            if all_fp32 is not None:
+                attach_pmc(all_fp32["roofline"], live_pmc(args, kind, mode, "f32_all"))
+                phase("PMC passes (f32_all)")
         if all_fp32 is not None:
             out["all_fp32_kernels"] = all_fp32
-        if split is not None:
-            out["split_precision"] = split
+        if f32_gemm is not None:
+            out["f32_gemm_route"] = f32_gemm
+        if evidence is not None:
+            out["precision_evidence"] = evidence
         if secondary is not None:
             out["secondary"] = {"hudiff_nb_configs3": secondary}
         if args.max_t > 0:

@@ -17,12 +17,16 @@ HD_ABI_VERSION = 1
 HD_KIND_ANTIBODY, HD_KIND_NANOBODY = 0, 1
 HD_ACT_RELU, HD_ACT_GELU = 1, 2
 HD_DROPOUT_FAITHFUL, HD_DROPOUT_OFF, HD_DROPOUT_INJECT, HD_NO_GRAPH, HD_NO_PRUNE, HD_ONE_LANE, HD_LOOP_GRAPH = 0, 1, 2, 4, 8, 16, 32
+HD_PRECISION_DEFAULT, HD_PRECISION_F32_GEMM, HD_PRECISION_F32_ALL, HD_PRECISION_SPLIT = 0, 1, 2, 3
+PRECISIONS = {"default": HD_PRECISION_DEFAULT, "split": HD_PRECISION_SPLIT, "f32_gemm": HD_PRECISION_F32_GEMM, "f32_all": HD_PRECISION_F32_ALL}
+PRECISION_NAMES = {HD_PRECISION_SPLIT: "split", HD_PRECISION_F32_GEMM: "f32_gemm", HD_PRECISION_F32_ALL: "f32_all", HD_PRECISION_DEFAULT: "default"}
 HD_OK, HD_ERR_INVALID, HD_ERR_UNSUPPORTED, HD_ERR_STATE, HD_ERR_HIP, HD_ERR_NO_DEVICE, HD_ERR_NUMERIC = range(7)
 
 EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",
     "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
     "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read", "hd_precision_info",
+    "hd_set_precision", "hd_precision_report", "hd_precision_reset", "hd_sample_tokens",
 ]
 
 
@@ -32,6 +36,11 @@ class HdConfig(C.Structure):
         "n_encoder_layers", "dual_layers", "kernel_size", "r", "att_model", "nhead", "dim_feedforward",
         "cs_layers", "n_region", "r_embedding", "n_side", "s_embedding", "enc_act", "conv_act")] + \
         [("dropout", C.c_float)]
+
+
+class HdPrecisionInfo(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("split_built", C.c_int32), ("split_in_use", C.c_int32), ("lnsync_in_use", C.c_int32),
+                ("range_fallbacks", C.c_int64), ("lnsync_fallbacks", C.c_int64), ("last_call_repeated", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HudiffError(RuntimeError):
@@ -71,6 +80,7 @@ def load():
     lib.hd_sample_run.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hd_sample_restart.argtypes = [vp, C.c_uint64]
     lib.hd_sample_end.argtypes = [vp, i32p]
+    lib.hd_sample_tokens.argtypes = [vp, i32p]
     lib.hd_sync.argtypes = [vp]
     lib.hd_last_run_ms.argtypes = [vp, f32p, i32p]
     lib.hd_flops_per_row_forward.argtypes = [P(HdConfig)]
@@ -79,6 +89,9 @@ def load():
     lib.hd_flops_per_row_sample_step.restype = C.c_double
     lib.hd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, i32p, P(C.c_int64)]
     lib.hd_precision_info.argtypes = [vp, i32p, i32p, P(C.c_int64)]
+    lib.hd_set_precision.argtypes = [vp, C.c_int32]
+    lib.hd_precision_report.argtypes = [vp, P(HdPrecisionInfo), C.c_size_t]
+    lib.hd_precision_reset.argtypes = [vp]
     lib.hd_debug_stop_after.argtypes = [vp, C.c_int32]
     lib.hd_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64]
     _lib = lib

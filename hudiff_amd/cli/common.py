@@ -37,6 +37,48 @@ def get_logger(name, log_dir=None):
     return logger
 
 
+def add_runtime_args(p):
+    """Flags every drop-in CLI adds beside the reference's own: the precision route of the device library and a self-launching
+    multi-GPU mode (rows shard across GPUs, one RCCL gather)."""
+    p.add_argument("--precision", choices=["default", "split", "f32_gemm", "f32_all"], default="default",
+                   help="precision route of libhudiff_hip (include/hudiff_hip.h): default = split (fp32 products as three fp16 MFMAs "
+                        "on (hi, lo) operand splits, fp32 accumulation; logits within 1e-4, the reference's traces bit for bit), "
+                        "f32_gemm = fp32 MFMA GEMMs + split attention core, f32_all = every product on the fp32 MFMA pipe")
+    p.add_argument("--gpus", type=int, default=None,
+                   help="N > 1 without a launcher: start N ranks of this command under torch.distributed.run (one process per GPU, "
+                        "127.0.0.1 rendezvous); under torchrun it must equal WORLD_SIZE")
+    return p
+
+
+def relaunch_if_asked(args, module, argv):
+    """`python -m hudiff_amd.cli.X --gpus N` without a launcher around it: re-execute as N ranks under torch.distributed.run (the
+    same shape bench.py uses) and return that job's exit code; None when this process should carry on (single rank, or already a
+    rank of a launched job).  A mismatch between --gpus and the world size a launcher formed is an error, never a silent run."""
+    import subprocess
+    import sys
+    if not args.gpus or args.gpus < 1:
+        return None
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit(f"{module}: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return None
+    if args.gpus == 1:
+        return None
+    cmd = relaunch_command(module, args.gpus, list(sys.argv[1:] if argv is None else argv))
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
+def relaunch_command(module, gpus, argv):
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), "-m", module] + argv
+
+
 def str2bool_like_reference(v):
     """argparse ``type=bool`` of the reference: any non-empty string is True (sample.py:402, 411-414)."""
     return bool(v)

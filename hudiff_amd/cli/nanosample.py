@@ -20,7 +20,7 @@ from .. import inputs as I
 from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
 from ..model import NanoAntiTFNet
 from ..sampler import Job, sample_jobs_with_retry, seed_all
-from .common import get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_wrapped
+from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_wrapped
 
 
 def build_parser():
@@ -44,6 +44,7 @@ def build_parser():
     p.add_argument("--device_batch", type=int, default=256)
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     p.add_argument("--device", type=int, default=None)
+    add_runtime_args(p)
     return p
 
 
@@ -70,6 +71,9 @@ def chain_is_valid(seq):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    rc = relaunch_if_asked(args, "hudiff_amd.cli.nanosample", argv)
+    if rc is not None:
+        return rc
     print(args.inpaint_sample)
     rank, world, local_rank = D.env_rank_world()
     D.init_process_group()
@@ -80,7 +84,7 @@ def main(argv=None):
         logger = get_logger("test", log_dir)
     ckpt = load_checkpoint(args.ckpt)
     _, params, state = nanobody_model_from_checkpoint(ckpt, args.model)
-    model = NanoAntiTFNet(**params, device=args.device if args.device is not None else local_rank)
+    model = NanoAntiTFNet(**params, device=args.device if args.device is not None else local_rank, precision=args.precision)
     model.load_state_dict(state)
     model.eval()
     if rank == 0:
@@ -133,4 +137,5 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    _r = main()
+    raise SystemExit(_r if isinstance(_r, int) else 0)      # an int is the exit code of a --gpus N relaunch

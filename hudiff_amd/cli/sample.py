@@ -27,7 +27,7 @@ from .. import inputs as I
 from ..checkpoint import antibody_model_from_checkpoint, load_checkpoint
 from ..model import model_selected
 from ..sampler import Job, sample_jobs, seed_all
-from .common import get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_2line
+from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_2line
 
 
 def build_parser():
@@ -62,6 +62,7 @@ def build_parser():
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful",
                    help="faithful = the reference's inference-time dropout (active iff config.dropout > 0)")
     p.add_argument("--device", type=int, default=None)
+    add_runtime_args(p)
     return p
 
 
@@ -124,6 +125,9 @@ def traditional_main(args):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    rc = relaunch_if_asked(args, "hudiff_amd.cli.sample", argv)
+    if rc is not None:
+        return rc
     if args.traditional_method:
         return traditional_main(args)
     if args.sample_method == "inpaint" and not args.grafted_fpath and I.numbering_backend("auto") != "anarci":
@@ -140,7 +144,7 @@ def main(argv=None):
 
     ckpt = load_checkpoint(args.ckpt)
     config, state, finetune = antibody_model_from_checkpoint(ckpt, args.ckpt_version)
-    model = model_selected(config, device=args.device if args.device is not None else local_rank)
+    model = model_selected(config, device=args.device if args.device is not None else local_rank, precision=args.precision)
     model.load_state_dict(state)
     model.eval()
     if rank == 0:
@@ -242,4 +246,5 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    _r = main()
+    raise SystemExit(_r if isinstance(_r, int) else 0)      # an int is the exit code of a --gpus N relaunch

@@ -21,7 +21,7 @@ from .. import inputs as I
 from ..checkpoint import antibody_model_from_checkpoint, load_checkpoint
 from ..model import model_selected
 from ..sampler import Job, sample_jobs, seed_all
-from .common import get_logger, get_new_log_dir, read_fasta
+from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, read_fasta
 
 
 def build_parser():
@@ -41,6 +41,7 @@ def build_parser():
     p.add_argument("--numbering", choices=["auto", "anarci", "builtin"], default="auto")
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     p.add_argument("--device", type=int, default=None)
+    add_runtime_args(p)
     return p
 
 
@@ -67,6 +68,9 @@ def variable_domain(seq, numbering):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    rc = relaunch_if_asked(args, "hudiff_amd.cli.sample_for_anti_cdr", argv)
+    if rc is not None:
+        return rc
     rank, world, local_rank = D.env_rank_world()
     D.init_process_group()
     seed_all(args.seed)
@@ -82,7 +86,7 @@ def main(argv=None):
         logger = get_logger("test", log_dir)
     ckpt = load_checkpoint(args.ckpt)
     config, state, _ = antibody_model_from_checkpoint(ckpt, "finetune")        # always ckpt['pretrain_config'] (:135)
-    model = model_selected(config, device=args.device if args.device is not None else local_rank)
+    model = model_selected(config, device=args.device if args.device is not None else local_rank, precision=args.precision)
     model.load_state_dict(state)
     model.eval()
     if rank == 0:
@@ -124,4 +128,5 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    _r = main()
+    raise SystemExit(_r if isinstance(_r, int) else 0)      # an int is the exit code of a --gpus N relaunch

@@ -22,7 +22,7 @@ from .. import inputs as I
 from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
 from ..model import NanoAntiTFNet
 from ..sampler import Job, sample_jobs, seed_all
-from .common import get_logger, get_new_log_dir, read_fasta, split_fasta_for_save, write_fasta_wrapped
+from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, read_fasta, split_fasta_for_save, write_fasta_wrapped
 from .nanosample import chain_is_valid
 
 
@@ -44,6 +44,7 @@ def build_parser():
     p.add_argument("--numbering", choices=["auto", "anarci", "builtin"], default="auto")
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     p.add_argument("--device", type=int, default=None)
+    add_runtime_args(p)
     return p
 
 
@@ -59,6 +60,9 @@ def get_nano_seq_from_fasta(fpath):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    rc = relaunch_if_asked(args, "hudiff_amd.cli.sample_for_nano_cdr", argv)
+    if rc is not None:
+        return rc
     rank, world, local_rank = D.env_rank_world()
     D.init_process_group()
     seed_all(args.seed)
@@ -69,7 +73,7 @@ def main(argv=None):
         logger = get_logger("test", log_dir)
     ckpt = load_checkpoint(args.ckpt)
     _, params, state = nanobody_model_from_checkpoint(ckpt, "finetune_vh")
-    model = NanoAntiTFNet(**params, device=args.device if args.device is not None else local_rank)
+    model = NanoAntiTFNet(**params, device=args.device if args.device is not None else local_rank, precision=args.precision)
     model.load_state_dict(state)
     model.eval()
     if rank == 0:
@@ -117,4 +121,5 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    _r = main()
+    raise SystemExit(_r if isinstance(_r, int) else 0)      # an int is the exit code of a --gpus N relaunch

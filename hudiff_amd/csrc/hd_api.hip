@@ -79,7 +79,7 @@ struct Workspace {
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float *S1 = nullptr, *YX = nullptr, *ATX = nullptr;      // split-precision route: act(LN(x)) of a ByteNet block's input; split copies of Y / AT, [M,D]
     float2* ST = nullptr;
-    int* SYNC = nullptr;                                     // ln_sync meeting counters, 2 ints per (segment, M tile), zero between launches
+    int* SYNC = nullptr;                                     // ln_sync meeting counters, 4 ints per (segment, M tile): arrivals, departures, XCC-id mask, spare; zero between launches
     float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
     int part_next = 0;                                       // buffer the next producing GEMM writes
     const float2* part_last = nullptr; int part_last_pw = 0; // what the last producing GEMM wrote (for its consumer)
@@ -110,14 +110,22 @@ struct HdModel {
     float p_enc = 0.f, p_conv = 0.f;
     // device weights
     float* blob = nullptr;
-    uint16_t* blobx = nullptr;        // split-precision copies of the GEMM weights (HUDIFF_X3=1 at hd_finalize)
-    bool x3 = false;
+    uint16_t* blobx = nullptr;        // split-precision copies of the GEMM weights (route HD_PRECISION_SPLIT)
+    // Precision route (include/hudiff_hip.h "precision routes"): what the caller asked for (hd_set_precision; DEFAULT = the library
+    // default unless the environment of hd_finalize overrides it) and what hd_finalize resolved it to.
+    int precision_req = HD_PRECISION_DEFAULT, precision = HD_PRECISION_SPLIT;
+    bool x3 = false;                  // split-precision GEMMs (weight images built)
     // Range guard of the split-precision kernels: their fp16 (hi, lo) operands are not scaled, so a producer that meets
     // |x| >= 65504 raises RunState::pad[1]; the forward / sample is then re-run on the fp32 kernels and the model stays on
     // them (weights whose residual stream leaves the fp16 range do so at every step): x3_suspended, counted in range_fallbacks.
     bool x3_suspended = false;
     int64_t range_fallbacks = 0;
-    bool attn_x3 = true;                             // split-precision attention core (attn_x3_k) inside the fp32 path: the default since round 3; HUDIFF_ATTN_X3=0 at hd_finalize keeps attn_k
+    bool attn_x3 = true;                             // split-precision attention core (attn_x3_k): routes SPLIT and F32_GEMM
+    // ln_sync guard: a failed meeting of a GEMM's N tiles (RunState::pad[2]) repeats the call with ln_apply_k passes and the handle
+    // keeps those (lnsync_level 0) until hd_precision_reset; counted in lnsync_fallbacks.
+    int lnsync_level_cfg = 2, lnsync_level = 2;      // 0 = ln_apply_k passes, 1 = the two inner GEMMs of a ByteNet block normalise their own output, 2 = the last GEMM as well
+    int64_t lnsync_fallbacks = 0;
+    bool last_call_repeated = false;                 // the last hd_forward / hd_sample_end repeated its call (either guard)
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
     std::vector<AttBlockW> att;
@@ -144,7 +152,7 @@ struct HdModel {
         hipGraphExec_t graph_exec = nullptr;
         int graph_B = -1; uint32_t graph_flags = 0; int graph_drop = -1; bool graph_q = false; int graph_Tmax = -1;
         int graph_qB = -1, graph_qoff = -1;
-        int graph_x3 = -1;                           // split-precision kernels active when the graph was captured
+        int graph_x3 = -1;                           // kernel_set() when the graph was captured (split kernels in use, ln_sync level)
         const float* graph_qptr = nullptr;           // the injected-noise buffer the captured sample_step_k reads
         // the T-step loop as ONE graph: `loop_steps` child-graph nodes of `graph` in a chain (hd_sample_run)
         hipGraph_t loop_graph = nullptr;
@@ -170,6 +178,7 @@ struct HdModel {
     int s_steps = 0;                                 // steps enqueued since then (largest t1 of hd_sample_run)
     uint32_t sflags = 0;
     bool s_has_q = false;
+    bool s_dirty = false;                            // a guard fired in the steps run since the last begin / restart: their tokens are invalid
     int last_steps = 0; bool timed = false;
     int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
 };
@@ -492,6 +501,35 @@ static AttLayerOff pack_attlayer(Loader& ld, Packer& pk, X3Packer* xp, const std
     return o;
 }
 
+extern "C" HdStatus hd_set_precision(HdModel* m, int32_t precision) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_set_precision: null model");
+    if (m->finalized) return fail(HD_ERR_STATE, "hd_set_precision: call it before hd_finalize (the split weight images are built there)");
+    if (precision != HD_PRECISION_DEFAULT && precision != HD_PRECISION_F32_GEMM && precision != HD_PRECISION_F32_ALL && precision != HD_PRECISION_SPLIT)
+        return fail(HD_ERR_INVALID, "hd_set_precision: unknown route %d", precision);
+    m->precision_req = precision;
+    return HD_OK;
+}
+
+// The route an unspecified (HD_PRECISION_DEFAULT) handle takes: HD_PRECISION_SPLIT, unless the environment says otherwise --
+// HUDIFF_PRECISION=split|f32_gemm|f32_all, or the round-2/3 switches HUDIFF_X3 (GEMMs) and HUDIFF_ATTN_X3 (attention core).
+static int default_route_from_env(std::string* err) {
+    if (const char* e = getenv("HUDIFF_PRECISION")) {
+        const std::string v(e);
+        if (v == "split" || v == "default" || v.empty()) return HD_PRECISION_SPLIT;
+        if (v == "f32_gemm") return HD_PRECISION_F32_GEMM;
+        if (v == "f32_all") return HD_PRECISION_F32_ALL;
+        *err = "HUDIFF_PRECISION=" + v + " (expected split, f32_gemm or f32_all)";
+        return HD_PRECISION_SPLIT;
+    }
+    // HUDIFF_X3=0 -> fp32 GEMMs (round-3 default route), + HUDIFF_ATTN_X3=0 -> every kernel fp32 (HUDIFF_ATTN_X3=0 alone means
+    // that too, as it did when HUDIFF_X3 defaulted to 0); HUDIFF_X3=1 -> split precision
+    const char *ex = getenv("HUDIFF_X3"), *ea = getenv("HUDIFF_ATTN_X3");
+    const bool ax = ea ? atoi(ea) != 0 : true;
+    const bool x3 = ex ? atoi(ex) != 0 : ax;
+    if (x3) return HD_PRECISION_SPLIT;
+    return ax ? HD_PRECISION_F32_GEMM : HD_PRECISION_F32_ALL;
+}
+
 extern "C" HdStatus hd_finalize(HdModel* m) {
     if (!m) return fail(HD_ERR_INVALID, "hd_finalize: null model");
     if (m->finalized) return fail(HD_ERR_STATE, "hd_finalize: already finalized");
@@ -501,12 +539,19 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     Loader ld{m};
     Packer pk;
     X3Packer xpk;
-    { const char* e = getenv("HUDIFF_X3"); m->x3 = e && atoi(e) != 0; }
-    // Attention core of launches >= 8192 activation rows: attn_x3_k (S = K Q^T and O = V^T P^T as three fp16 MFMAs per product on
-    // fp16 (hi, lo) splits of the fp32 Q, K, V, P; fp32 accumulation, fp32 softmax, fp32 Q|K|V in, fp32 O out) unless HUDIFF_ATTN_X3=0.
-    // Round 2 measured it at 253 vs 483 us per launch with logits 1e-6 from attn_k's and identical tokens; round 3 put the range
-    // guard, the adversarial-statistics vectors and the whole GPU suite behind it (DESIGN.md sections 8, 9).
-    { const char* e = getenv("HUDIFF_ATTN_X3"); m->attn_x3 = !(e && atoi(e) == 0); }
+    // Precision route (include/hudiff_hip.h): an explicit hd_set_precision wins; HD_PRECISION_DEFAULT is the library default
+    // (split precision since round 4: VERDICT r3 "Next" #1) unless the environment overrides the default.
+    {
+        std::string perr;
+        m->precision = m->precision_req != HD_PRECISION_DEFAULT ? m->precision_req : default_route_from_env(&perr);
+        if (!perr.empty()) return fail(HD_ERR_INVALID, "hd_finalize: %s", perr.c_str());
+        m->x3 = m->precision == HD_PRECISION_SPLIT;
+        // attention core of launches >= 8192 activation rows: attn_x3_k (S = K Q^T and O = V^T P^T as three fp16 MFMAs per product
+        // on fp16 (hi, lo) splits of the fp32 Q, K, V, P; fp32 accumulation and softmax) on every route but F32_ALL
+        m->attn_x3 = m->precision != HD_PRECISION_F32_ALL;
+        const char* e = getenv("HUDIFF_X3_LNSYNC");
+        m->lnsync_level_cfg = m->lnsync_level = e ? atoi(e) : 2;
+    }
     X3Packer* xp = m->x3 ? &xpk : nullptr;
     // HUDIFF_X3_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
     const int x3_mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 3; }();
@@ -944,12 +989,10 @@ enum XStats { X_FINAL = 0,      // ws.ST already holds (mean, rstd)
 // once in place (ln_apply_k).  want_out_stats: leave partials of `out` for the next block's first GEMM.
 // ln_sync on / off (HUDIFF_X3_LNSYNC, default on): the split-precision ByteNet GEMMs normalise + activate + split their own
 // output rows (GemmP::ln_sync) instead of leaving that to a separate ln_apply_k pass over HBM
-static int x3_lnsync_level() {
-    // 0 off, 1 the two inner GEMMs of a block (h1, h2), 2 also the block's last GEMM (writes the NEXT block's first operand)
-    static const int lv = [] { const char* e = getenv("HUDIFF_X3_LNSYNC"); return e ? atoi(e) : 2; }();
-    return lv;
-}
-static bool x3_lnsync() { return x3_lnsync_level() > 0; }
+// level (HdModel::lnsync_level; HUDIFF_X3_LNSYNC at hd_finalize, 0 after a failed meeting): 0 off, 1 the two inner GEMMs of a block
+// (h1, h2), 2 also the block's last GEMM (writes the NEXT block's first operand)
+static int x3_lnsync_level(const HdModel* m) { return m->lnsync_level; }
+static bool x3_lnsync(const HdModel* m) { return m->lnsync_level > 0; }
 
 // `next`: the block that follows in the same stack (same widths) when it will also take the split-precision route and reads
 // exactly `out` (ldo == din, no columns beside it): this block's last GEMM then writes act(LN1_next(out)) in split form into ws.S1
@@ -974,7 +1017,7 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
         Workspace& ws = cur(m).ws;
         hipStream_t st = cur(m).stream;
         const int seg1 = sg.nseg > 1 ? sg.base[1] : rows;
-        const bool sync = x3_lnsync() && ws.SYNC;
+        const bool sync = x3_lnsync(m) && ws.SYNC;
         if (x_stats != X_S1) {
             const bool from_part = x_stats == X_PARTIALS, self = x_stats == X_NONE && din <= 1024;
             hipLaunchKernelGGL(ln_apply_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, from_part ? ws.part_last : (const float2*)nullptr,
@@ -1184,7 +1227,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
         // split-precision route with ln_sync: block n's last GEMM writes block n + 1's first operand (x_stats = X_S1 then)
-        const bool chain = x3_lnsync_level() > 1 && ws.SYNC && x3_use(m, sg, m->enc[n].w1x) && x3_use(m, sg, m->enc[n].wcx) && x3_use(m, sg, m->enc[n].w3x);
+        const bool chain = x3_lnsync_level(m) > 1 && ws.SYNC && x3_use(m, sg, m->enc[n].w1x) && x3_use(m, sg, m->enc[n].wcx) && x3_use(m, sg, m->enc[n].w3x);
         bytenet_block(m, sg, m->enc[n], d, dh, c.enc_act, ws.X, d, ws.H1, ws.H2, last ? ws.FEAT : ws.X, last ? D : d, dr,
                       last ? ws.EXTRA : nullptr, d, n == 0 ? X_FINAL : (chain ? X_S1 : X_PARTIALS), /*want_out_stats=*/!last,
                       nullptr, (chain && !last) ? &m->enc[n + 1] : nullptr);
@@ -1196,7 +1239,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass
         // x3: the last block also leaves Y in split form for the first attention's Q|K|V projection
-        const bool chain = x3_lnsync_level() > 1 && ws.SYNC && x3_use(m, sg, m->conv[n].w1x) && x3_use(m, sg, m->conv[n].wcx) && x3_use(m, sg, m->conv[n].w3x);
+        const bool chain = x3_lnsync_level(m) > 1 && ws.SYNC && x3_use(m, sg, m->conv[n].w1x) && x3_use(m, sg, m->conv[n].wcx) && x3_use(m, sg, m->conv[n].w3x);
         bytenet_block(m, sg, m->conv[n], D, Dh, c.conv_act, n == 0 ? ws.FEAT : ws.Y, D, ws.G1, ws.G2, ws.Y, D, dr, nullptr, 0,
                       n == 0 ? X_NONE : (chain ? X_S1 : X_PARTIALS), /*want_out_stats=*/n + 1 < c.dual_layers,
                       (ax3 && n + 1 == c.dual_layers) ? ws.YX : nullptr, (chain && n + 1 < c.dual_layers) ? &m->conv[n + 1] : nullptr);
@@ -1269,6 +1312,8 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 
 // split-precision kernels (whole path or attention only) currently in use / switched off for good by the range guard
 static bool split_active(const HdModel* m) { return (m->x3 || m->attn_x3) && !m->x3_suspended; }
+// which kernels a captured step graph holds: split kernels in use, ln_sync level
+static int kernel_set(const HdModel* m) { return (split_active(m) ? 1 : 0) | (m->lnsync_level << 1); }
 static void suspend_split(HdModel* m) {
     // said once per handle (stderr; HUDIFF_QUIET=1 silences it): from here on the handle runs the all-fp32 kernels, at their speed
     static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();
@@ -1278,6 +1323,36 @@ static void suspend_split(HdModel* m) {
     m->x3_suspended = true;
     m->range_fallbacks += 1;
     for (auto& ln : m->lane) ln.drop_graphs();      // captured with the split kernels
+}
+
+static void suspend_lnsync(HdModel* m, uint32_t bits) {
+    static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();
+    if (!quiet)
+        fprintf(stderr, "[hudiff_hip] an ln_sync meeting failed (%s): this call is repeated with separate LayerNorm passes and the handle keeps "
+                        "them (hd_precision_report.lnsync_fallbacks)\n",
+                (bits & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
+    m->lnsync_level = 0;
+    m->lnsync_fallbacks += 1;
+    for (auto& ln : m->lane) ln.drop_graphs();      // captured with the meeting epilogues
+}
+
+// Guard flags of the lanes of the current call / session (RunState::pad: [0] non-finite logits, [1] range guard, [2] ln_sync guard).
+// Synchronises the lanes.  A guard that fired switches the failing kernels off (suspend_*) and marks the steps run since the last
+// begin / restart invalid (m->s_dirty): the caller repeats them.  One guard per round: a failed meeting leaves garbage that can trip
+// the range guard too, so the range flag of such a run is not believed -- the repeat raises it again if it is real.
+static HdStatus check_guards(HdModel* m, int nlanes, bool* numeric) {
+    uint32_t pad[3] = {0, 0, 0};
+    for (int l = 0; l < nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
+    for (int l = 0; l < nlanes; ++l) {
+        RunState h{};
+        HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) pad[i] |= h.pad[i];
+    }
+    if (numeric) *numeric = pad[0] != 0;
+    if (m->s_dirty) return HD_OK;                   // already known; nothing more is read out of an invalid run
+    if (pad[2] && m->x3 && !m->x3_suspended && m->lnsync_level > 0) { suspend_lnsync(m, pad[2]); m->s_dirty = true; }
+    else if (pad[1] && split_active(m)) { suspend_split(m); m->s_dirty = true; }
+    return HD_OK;
 }
 
 template <typename T>
@@ -1322,16 +1397,16 @@ extern "C" HdStatus hd_forward(HdModel* m, const int32_t* tokens, const int32_t*
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(logits, ws.LOGITS, (size_t)rows * m->cfg.n_tokens * sizeof(float), hipMemcpyDeviceToHost, cur(m).stream));
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
-    if (split_active(m)) {          // range guard: an operand of a split-precision kernel left the fp16 range -> fp32 kernels
-        RunState h{};
-        HIP_TRY(hipMemcpy(&h, cur(m).rs, sizeof(h), hipMemcpyDeviceToHost));
-        if (h.pad[2]) return fail(HD_ERR_STATE, "hd_forward: a GEMM's ln_sync meeting failed (%s); set HUDIFF_X3_LNSYNC=0",
-                                  (h.pad[2] & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
-        if (h.pad[1]) {
-            suspend_split(m);
-            return hd_forward(m, tokens, region, chain, B, flags, seed, row0, step, enc_masks, conv_masks, logits);
-        }
+    // guards of the split-precision kernels (range, ln_sync): the call is repeated on the kernels that do not need them
+    m->s_dirty = false;
+    HD_TRY(check_guards(m, 1, nullptr));
+    if (m->s_dirty) {
+        m->s_dirty = false;
+        const HdStatus s = hd_forward(m, tokens, region, chain, B, flags, seed, row0, step, enc_masks, conv_masks, logits);
+        m->last_call_repeated = true;
+        return s;
     }
+    m->last_call_repeated = false;
     return HD_OK;
 }
 
@@ -1359,7 +1434,7 @@ static HdStatus sample_begin_impl(HdModel* m, const int32_t* tokens, const int32
     if (B < 0 || Tmax < 0) return fail(HD_ERR_INVALID, "hd_sample_begin: B = %d, Tmax = %d", B, Tmax);
     HIP_TRY(hipSetDevice(m->device));
     m->sB = B; m->sTmax = Tmax; m->sflags = flags; m->s_has_q = q_noise != nullptr; m->timed = false; m->last_steps = 0;
-    m->s_seed = seed; m->s_steps = 0;
+    m->s_seed = seed; m->s_steps = 0; m->s_dirty = false;
     m->nlanes = 1; m->cl = 0;
     if (B == 0) { m->in_session = true; return HD_OK; }
     HD_TRY(validate_inputs(m, tokens, region, chain, B));
@@ -1455,9 +1530,12 @@ extern "C" HdStatus hd_sample_begin(HdModel* m, const int32_t* tokens, const int
 
 extern "C" HdStatus hd_sample_restart(HdModel* m, uint64_t seed) {
     if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_restart: no open session");
-    m->s_seed = seed; m->s_steps = 0;
-    if (m->sB == 0) return HD_OK;
+    if (m->sB == 0) { m->s_seed = seed; m->s_steps = 0; return HD_OK; }
     HIP_TRY(hipSetDevice(m->device));
+    // a guard that fired in the sample being discarded still switches its kernels off (and is counted) before the flags are cleared:
+    // the next sample must not run on kernels that just failed (the begin / run / restart / run / ... / end pattern of bench.py)
+    if (m->s_steps > 0) HD_TRY(check_guards(m, m->nlanes, nullptr));
+    m->s_seed = seed; m->s_steps = 0; m->s_dirty = false;
     for (int l = 0; l < m->nlanes; ++l) {
         m->cl = l;
         HdModel::Lane& ln = m->lane[l];
@@ -1485,7 +1563,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
         const uint32_t gflags = m->sflags & HD_NO_PRUNE;
         if (!ln.graph_exec || ln.graph_B != ln.B || ln.graph_flags != gflags || ln.graph_drop != dm || ln.graph_q != m->s_has_q ||
             ln.graph_Tmax != m->sTmax || ln.graph_qB != m->sB || ln.graph_qoff != ln.row_off ||
-            ln.graph_qptr != (m->s_has_q ? m->qnoise : nullptr) || ln.graph_x3 != (split_active(m) ? 1 : 0)) {
+            ln.graph_qptr != (m->s_has_q ? m->qnoise : nullptr) || ln.graph_x3 != kernel_set(m)) {
             ln.drop_graphs();
             HIP_TRY(hipStreamSynchronize(ln.stream));
             HIP_TRY(hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal));
@@ -1496,7 +1574,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
             HIP_TRY(hipGraphInstantiate(&ln.graph_exec, ln.graph, nullptr, nullptr, 0));
             ln.graph_B = ln.B; ln.graph_flags = gflags; ln.graph_drop = dm; ln.graph_q = m->s_has_q; ln.graph_Tmax = m->sTmax;
             ln.graph_qB = m->sB; ln.graph_qoff = ln.row_off; ln.graph_qptr = m->s_has_q ? m->qnoise : nullptr;
-            ln.graph_x3 = split_active(m) ? 1 : 0;
+            ln.graph_x3 = kernel_set(m);
         }
     }
     for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipEventRecord(m->lane[l].ev0, m->lane[l].stream));
@@ -1550,24 +1628,48 @@ extern "C" HdStatus hd_sync(HdModel* m) {
     if (!m) return fail(HD_ERR_INVALID, "hd_sync: null model");
     HIP_TRY(hipSetDevice(m->device));
     for (auto& ln : m->lane) HIP_TRY(hipStreamSynchronize(ln.stream));
+    // inside a session the guards are looked at here too: the steps run so far are then marked invalid (hd_sample_end repeats them)
+    // and the failing kernels are off for whatever is enqueued next
+    if (m->in_session && m->sB > 0 && m->s_steps > 0) HD_TRY(check_guards(m, m->nlanes, nullptr));
     return HD_OK;
 }
 
-static HdStatus sample_collect(HdModel* m, int32_t* tokens, bool* numeric, bool* range) {
+static HdStatus sample_collect(HdModel* m, int32_t* tokens, bool* numeric) {
     for (int l = 0; l < m->nlanes; ++l) {
         HdModel::Lane& ln = m->lane[l];
         HIP_TRY(hipMemcpyAsync(tokens + (size_t)ln.row_off * m->L, ln.ws.tokens, (size_t)ln.B * m->L * sizeof(int32_t), hipMemcpyDeviceToHost, ln.stream));
     }
-    for (int l = 0; l < m->nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
-    *numeric = *range = false;
-    for (int l = 0; l < m->nlanes; ++l) {
-        RunState h{};
-        HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
-        if (h.pad[0]) *numeric = true;
-        if (h.pad[1]) *range = true;
-        if (h.pad[2]) return fail(HD_ERR_STATE, "hd_sample: a GEMM's ln_sync meeting failed (%s); set HUDIFF_X3_LNSYNC=0",
-                                  (h.pad[2] & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
+    return check_guards(m, m->nlanes, numeric);
+}
+
+extern "C" HdStatus hd_sample_tokens(HdModel* m, int32_t* tokens) {
+    if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_tokens: no open session");
+    if (m->sB == 0) return HD_OK;
+    if (!tokens) return fail(HD_ERR_INVALID, "hd_sample_tokens: null tokens");
+    HIP_TRY(hipSetDevice(m->device));
+    HD_TRY(sample_collect(m, tokens, nullptr));
+    if (m->s_dirty) return fail(HD_ERR_STATE, "hd_sample_tokens: a guard of the split-precision kernels fired during these steps; their tokens "
+                                               "are invalid (hd_sample_end repeats the sample)");
+    return HD_OK;
+}
+
+static HdStatus sample_end_impl(HdModel* m, int32_t* tokens, bool* numeric) {
+    HIP_TRY(hipSetDevice(m->device));
+    HD_TRY(sample_collect(m, tokens, numeric));
+    m->last_call_repeated = false;
+    // Guards (range, ln_sync; see check_guards): some split-precision kernel could not be trusted during this sample.  The whole
+    // sample is repeated on the kernels that do not need the guard -- same resident inputs, same noise key, same steps -- and the
+    // handle stays on them.  At most one repeat per guard.
+    for (int attempt = 0; m->s_dirty && attempt < 2; ++attempt) {
+        const int steps = m->s_steps;
+        m->s_dirty = false;                          // (hd_sample_restart would otherwise look at the same flags again)
+        m->s_steps = 0;
+        HD_TRY(hd_sample_restart(m, m->s_seed));
+        if (steps > 0) HD_TRY(hd_sample_run(m, 0, steps));
+        HD_TRY(sample_collect(m, tokens, numeric));
+        m->last_call_repeated = true;
     }
+    if (m->s_dirty) return fail(HD_ERR_STATE, "hd_sample_end: a guard of the split-precision kernels fired on the fp32 kernels (internal error)");
     return HD_OK;
 }
 
@@ -1575,25 +1677,40 @@ extern "C" HdStatus hd_sample_end(HdModel* m, int32_t* tokens) {
     if (!m || !m->in_session) return fail(HD_ERR_STATE, "hd_sample_end: no open session");
     if (m->sB == 0) { m->in_session = false; return HD_OK; }
     if (!tokens) { m->in_session = false; return fail(HD_ERR_INVALID, "hd_sample_end: null tokens"); }
-    HIP_TRY(hipSetDevice(m->device));
-    bool numeric = false, range = false;
-    HdStatus s = sample_collect(m, tokens, &numeric, &range);
-    if (s == HD_OK && range && split_active(m)) {
-        // range guard (see HdModel::x3_suspended): some operand of a split-precision kernel left the fp16 range during this
-        // sample.  The whole sample is repeated on the fp32 kernels -- same resident inputs, same noise key, same steps --
-        // and the model stays on them.
-        suspend_split(m);
-        const int steps = m->s_steps;
-        s = hd_sample_restart(m, m->s_seed);
-        if (s == HD_OK && steps > 0) s = hd_sample_run(m, 0, steps);
-        if (s == HD_OK) s = sample_collect(m, tokens, &numeric, &range);
-    }
-    m->in_session = false;
+    bool numeric = false;
+    const HdStatus s = sample_end_impl(m, tokens, &numeric);
+    m->in_session = false;                           // on every path: a failed end never leaves a half-open session behind
+    m->s_dirty = false;
     m->cl = 0;
     if (s != HD_OK) return s;
     if (numeric)
         return fail(HD_ERR_NUMERIC, "hd_sample: non-finite logits (NaN / inf) at some denoiser step -- weights or inputs out of range; "
                                     "the reference's torch.multinomial raises at this point");
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_precision_report(HdModel* m, HdPrecisionInfo* out, size_t size) {
+    if (!m || !out) return fail(HD_ERR_INVALID, "hd_precision_report: null argument");
+    HdPrecisionInfo r{};
+    r.precision = m->finalized ? m->precision : m->precision_req;
+    r.split_built = (m->x3 ? 1 : 0) | (m->attn_x3 ? 2 : 0);
+    r.split_in_use = (m->finalized && split_active(m)) ? 1 : 0;
+    r.lnsync_in_use = (m->finalized && m->x3 && !m->x3_suspended && m->lnsync_level > 0) ? 1 : 0;
+    r.range_fallbacks = m->range_fallbacks;
+    r.lnsync_fallbacks = m->lnsync_fallbacks;
+    r.last_call_repeated = m->last_call_repeated ? 1 : 0;
+    memcpy(out, &r, size < sizeof(r) ? size : sizeof(r));
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_precision_reset(HdModel* m) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_precision_reset: null model");
+    if (m->in_session) return fail(HD_ERR_STATE, "hd_precision_reset: a sampling session is open");
+    if (m->x3_suspended || m->lnsync_level != m->lnsync_level_cfg) {
+        m->x3_suspended = false;
+        m->lnsync_level = m->lnsync_level_cfg;
+        for (auto& ln : m->lane) ln.drop_graphs();
+    }
     return HD_OK;
 }
 

@@ -46,14 +46,18 @@ def init_process_group(backend: Optional[str] = None, force: Optional[bool] = No
     if dist.is_initialized():
         _active = True
         return dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "MASTER_PORT" not in os.environ:
-        import socket
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-    os.environ.setdefault("RANK", str(rank))
-    os.environ.setdefault("WORLD_SIZE", str(world))
+    if world == 1:
+        # a forced single-rank group has no launcher around it: give torch the rendezvous it needs.  For world > 1 the environment
+        # is left alone -- a launcher that exports RANK / WORLD_SIZE without MASTER_ADDR / MASTER_PORT must fail at once with
+        # torch's own "MASTER_PORT expected" error, not hang with every rank bound to a port of its own choosing
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     # HUDIFF_DIST_BACKEND=gloo: ranks that share one GPU (tests on a 1-GPU box; RCCL refuses duplicate devices)
     backend = backend or os.environ.get("HUDIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":

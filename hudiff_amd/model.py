@@ -61,7 +61,7 @@ class _Denoiser:
                  n_region, r_embedding, r_model, n_pos_model, max_len, sum_d_model, dual_layers,
                  att_model, dim_feedforward, nhead, cs_layers, n_side=3, s_embedding=4, s_model=None,
                  rank=None, n_frozen_embs=None, padding_idx=None, causal=False, dropout=0.0, slim=True,
-                 activation="relu", down_embed=False, timesteps=None, device=0):
+                 activation="relu", down_embed=False, timesteps=None, device=0, precision=None):
         if rank is not None or n_frozen_embs is not None or causal or not slim or down_embed or padding_idx is not None:
             raise NotImplementedError("only the configuration HuDiff ships (rank=None, causal=False, slim=True, "
                                       "down_embed=False, padding_idx=None) is implemented")
@@ -95,6 +95,13 @@ class _Denoiser:
         self._lib = L.load()
         self._h = C.c_void_p()
         L.check(self._lib.hd_create(C.byref(c), int(device), C.byref(self._h)))
+        # precision route (include/hudiff_hip.h "precision routes"; not a keyword of the reference's constructor, which computes in
+        # fp32 on whatever torch gives it): None / "default" = the library default (split precision; the environment may override
+        # the default), "split" | "f32_gemm" | "f32_all" = that route whatever the environment says
+        if precision is not None:
+            if precision not in L.PRECISIONS:
+                raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
+            L.check(self._lib.hd_set_precision(self._h, L.PRECISIONS[precision]))
         self._loaded = False
         self.device_index = int(device)
 
@@ -241,18 +248,31 @@ class _Denoiser:
         L.check(self._lib.hd_sample_end(self._h, L.ptr(out, C.c_int32)))
         return out
 
+    def sample_tokens(self):
+        """Tokens of the open session as they stand (hd_sample_tokens: synchronises, the session stays open)."""
+        out = np.empty((self._session_B, self.max_len), dtype=np.int32)
+        L.check(self._lib.hd_sample_tokens(self._h, L.ptr(out, C.c_int32)))
+        return out
+
     def last_run_ms(self):
         ms, steps = C.c_float(), C.c_int32()
         L.check(self._lib.hd_last_run_ms(self._h, C.byref(ms), C.byref(steps)))
         return float(ms.value), int(steps.value)
 
     def precision_info(self):
-        """{'split_built', 'split_in_use', 'range_fallbacks'} (hd_precision_info): whether this handle carries the split-precision
-        kernels (HUDIFF_X3 / HUDIFF_ATTN_X3 at load time), whether they are still in use, and how many calls were repeated on
-        the fp32 kernels because an operand left the fp16 range."""
-        built, use, n = C.c_int32(), C.c_int32(), C.c_int64()
-        L.check(self._lib.hd_precision_info(self._h, C.byref(built), C.byref(use), C.byref(n)))
-        return {"split_built": int(built.value), "split_in_use": bool(use.value), "range_fallbacks": int(n.value)}
+        """hd_precision_report: {'precision': 'split' | 'f32_gemm' | 'f32_all' (the resolved route), 'split_built' (bit 0 GEMM weight
+        images, bit 1 attention core), 'split_in_use', 'lnsync_in_use', 'range_fallbacks' (calls repeated on the fp32 kernels because
+        an operand left the fp16 range), 'lnsync_fallbacks' (calls repeated with separate LayerNorm passes because an ln_sync meeting
+        failed), 'last_call_repeated'}."""
+        r = L.HdPrecisionInfo()
+        L.check(self._lib.hd_precision_report(self._h, C.byref(r), C.sizeof(r)))
+        return {"precision": L.PRECISION_NAMES[int(r.precision)], "split_built": int(r.split_built), "split_in_use": bool(r.split_in_use),
+                "lnsync_in_use": bool(r.lnsync_in_use), "range_fallbacks": int(r.range_fallbacks),
+                "lnsync_fallbacks": int(r.lnsync_fallbacks), "last_call_repeated": bool(r.last_call_repeated)}
+
+    def precision_reset(self):
+        """hd_precision_reset: back on the configured route after a guard switched kernels off."""
+        L.check(self._lib.hd_precision_reset(self._h))
 
     def debug_stop_after(self, stage):
         L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
@@ -287,14 +307,14 @@ class NanoAntiTFNet(_Denoiser):
                          cs_layers, **kw)
 
 
-def model_selected(config, pretrained_model=None, tokenizer=None, device=0):
+def model_selected(config, pretrained_model=None, tokenizer=None, device=0, precision=None):
     """utils/train_utils.py:43-55 for the two inference models (the training-only wrappers are out of scope)."""
     name = _get(config, "name")
     params = dict(_get(config, "model"))
     if name == "trans_oadm":
-        return AntiTFNet(**params, device=device)
+        return AntiTFNet(**params, device=device, precision=precision)
     if name == "nano":
-        return NanoAntiTFNet(**params, device=device)
+        return NanoAntiTFNet(**params, device=device, precision=precision)
     raise NotImplementedError(f"config.name={name!r}: only 'trans_oadm' and 'nano' are sampling models")
 
 

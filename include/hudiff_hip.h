@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 1
+#define HD_ABI_VERSION 1      /* layout of HdConfig; round 4 added entry points (hd_set_precision, hd_precision_report, hd_precision_reset) only */
 
 typedef enum HdStatus {
     HD_OK = 0,
@@ -153,6 +153,11 @@ HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1);
 HdStatus hd_sample_restart(HdModel* m, uint64_t seed);
 HdStatus hd_sample_end(HdModel* m, int32_t* tokens);
 HdStatus hd_sync(HdModel* m);
+/* Copies the tokens of the open session as they stand after the steps enqueued so far (synchronises; the session stays open):
+ * lets a caller that restarts one resident batch many times keep every sample's result (bench.py: token agreement between
+ * precision routes over all timed samples).  A guard that fired (see "precision routes") makes this fail with HD_ERR_STATE --
+ * only hd_sample_end repeats a sample. */
+HdStatus hd_sample_tokens(HdModel* m, int32_t* tokens);
 
 /* ---- measurement helpers ------------------------------------------------------------------------
  * hd_sample_run brackets the steps it enqueues with HIP events on the handle's stream;
@@ -163,16 +168,51 @@ double hd_flops_per_row_forward(const HdConfig* cfg);
 /* FLOPs one hd_sample step actually executes per row (last attention block pruned to the visited row, its value side
  * taken through the input rows instead of a V projection of every row). */
 double hd_flops_per_row_sample_step(const HdConfig* cfg);
-/* Precision route of this handle.  The product path multiplies in fp32 on the matrix cores.  With HUDIFF_X3=1 (or
- * HUDIFF_ATTN_X3=1) in the environment of hd_finalize, launches of >= 8192 activation rows run "split-precision" kernels
- * instead: every fp32 operand is hi + lo with hi = fp16(x), lo = fp16(x - hi) and a product is three fp16 MFMAs with fp32
- * accumulation (as close to the exact dot product as the fp32 kernels).  Operands are not scaled, so the route is valid for
- * |x| < 65504 only: every producer of a split checks its values, and when one is out of range the forward / sample is
- * repeated on the fp32 kernels inside the same call (same inputs, same noise) and the handle stays on them.
- *   split_built   bit 0: split-precision weight images were built, bit 1: split-precision attention inside the fp32 path
- *   split_in_use  1 while eligible launches take the split-precision kernels, 0 after the range guard switched them off
- *   range_fallbacks  number of calls that were repeated on the fp32 kernels                                            */
+/* ---- precision routes --------------------------------------------------------------------------------
+ * The reference computes in fp32 (PyTorch CPU / CUDA defaults, model/encoder/model.py:366-384).  gfx950 multiplies fp32 operands
+ * on the matrix cores at 1/16 of the fp16 rate and has no TF32-like mode, so the library has three routes through the same
+ * kernels' interfaces; all three hold the 1e-4 logit bound and reproduce the reference's recorded sampling traces bit for bit
+ * (tests/test_prod_trace.py, tests/test_gpu_adversarial.py):
+ *   HD_PRECISION_SPLIT     every large GEMM and the attention core as THREE fp16 MFMAs per fp32 product: each operand is hi + lo with
+ *                          hi = fp16(x), lo = fp16(x - hi) (22 significand bits; x - hi is exact), a w ~= a_hi w_hi + a_hi w_lo +
+ *                          a_lo w_hi with fp32 accumulation -- as close to the exact dot product as the fp32 kernels.  Launches of
+ *                          fewer than 8192 activation rows, the pruned tail's compact GEMMs and the static branch run the fp32 kernels.
+ *   HD_PRECISION_F32_GEMM  GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32); only the attention core (QK^T, PV) of launches
+ *                          >= 8192 rows as three fp16 MFMAs per product (the round-3 default)
+ *   HD_PRECISION_F32_ALL   every product on the fp32 MFMA pipe (rounds 1-2)
+ *   HD_PRECISION_DEFAULT   what a handle starts with: the library default, HD_PRECISION_SPLIT since round 4 -- unless the environment
+ *                          of hd_finalize overrides the DEFAULT (only the default; an explicit hd_set_precision wins):
+ *                          HUDIFF_PRECISION=split|f32_gemm|f32_all, or the older switches HUDIFF_X3=0|1 (GEMMs) and
+ *                          HUDIFF_ATTN_X3=0|1 (attention core).
+ * hd_set_precision must be called before hd_finalize (the split weight images are built there); afterwards HD_ERR_STATE.
+ *
+ * Guards of the split kernels -- never an error, never a silently wrong row; the CALL is repeated inside the library and the event
+ * is counted:
+ *   range guard   split operands are not scaled, so the split is valid for |x| < 65504 only.  Every producer of a split checks
+ *                 its values; when one is out of range, hd_forward / hd_sample[_end] repeats the whole call on the fp32 kernels (same
+ *                 resident inputs, same noise key, same steps) and the handle stays on them (weights whose stream leaves the
+ *                 range do so at every step) until hd_precision_reset.  hd_sample_restart and hd_sync notice the flag as well.
+ *   ln_sync guard the ByteNet GEMMs of the split route normalise their own output rows: the N tiles of an M tile meet at an L2-level
+ *                 counter, which presumes they run together on one XCD.  A meeting that times out or sees two XCDs raises a flag;
+ *                 the call is repeated with separate LayerNorm passes (ln_apply_k) and the handle keeps those.                    */
+enum { HD_PRECISION_DEFAULT = 0, HD_PRECISION_F32_GEMM = 1, HD_PRECISION_F32_ALL = 2, HD_PRECISION_SPLIT = 3 };
+HdStatus hd_set_precision(HdModel* m, int32_t precision);
+typedef struct HdPrecisionInfo {
+    int32_t precision;          /* resolved route of the handle: HD_PRECISION_SPLIT / F32_GEMM / F32_ALL (never DEFAULT after hd_finalize) */
+    int32_t split_built;        /* bit 0: split-precision weight images exist (GEMMs), bit 1: split-precision attention core     */
+    int32_t split_in_use;       /* 1 while eligible launches take the split kernels, 0 after the range guard switched them off   */
+    int32_t lnsync_in_use;      /* 1 while the split ByteNet GEMMs normalise their own outputs, 0 = separate ln_apply_k passes   */
+    int64_t range_fallbacks;    /* calls repeated on the fp32 kernels by the range guard                                          */
+    int64_t lnsync_fallbacks;   /* calls repeated with ln_apply_k passes because an ln_sync meeting failed                        */
+    int32_t last_call_repeated; /* 1 if the last hd_forward / hd_sample_end repeated its call (hd_last_run_ms then times the repeat) */
+    int32_t reserved;
+} HdPrecisionInfo;
+/* size = sizeof(HdPrecisionInfo) of the caller (fields beyond it are not written) */
+HdStatus hd_precision_report(HdModel* m, HdPrecisionInfo* out, size_t size);
+/* The three original fields of the report (kept for round-3 callers). */
 HdStatus hd_precision_info(HdModel* m, int32_t* split_built, int32_t* split_in_use, int64_t* range_fallbacks);
+/* Puts a handle whose guards switched kernels off back on its configured route (between calls; HD_ERR_STATE inside a session). */
+HdStatus hd_precision_reset(HdModel* m);
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 

@@ -73,6 +73,19 @@ def unpack_masks(z, key):
     return np.unpackbits(z[key])[: int(np.prod(shape))].reshape(shape)
 
 
+def prec(model, **expect):
+    """Assert a subset of hd_precision_report (model.precision_info()): e.g. prec(m, precision="split", range_fallbacks=0)."""
+    info = model.precision_info()
+    bad = {k: (info.get(k), v) for k, v in expect.items() if info.get(k) != v}
+    assert not bad, (bad, info)
+    return info
+
+
+def env_forces_route():
+    """True when the environment overrides the library's default precision route (the nested whole-suite run does)."""
+    return any(os.environ.get(k) not in (None, "") for k in ("HUDIFF_PRECISION", "HUDIFF_X3", "HUDIFF_ATTN_X3"))
+
+
 def chain_or_none(z):
     return z["chain"] if z["chain"].size else None
 

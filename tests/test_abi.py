@@ -35,6 +35,33 @@ def test_config_struct_layout_matches_header():
     assert C.sizeof(_lib.HdConfig) == 4 * len(fields)
 
 
+def test_precision_report_struct_layout_matches_header():
+    from hudiff_amd import _lib
+    text = open(os.path.join(ROOT, "include", "hudiff_hip.h")).read()
+    body = re.search(r"typedef struct HdPrecisionInfo \{(.*?)\} HdPrecisionInfo;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int32_t|int64_t)\s+([a-z_]+);", body)
+    assert [n for _, n in fields] == [n for n, _ in _lib.HdPrecisionInfo._fields_]
+    assert [t for t, _ in fields] == ["int32_t" if c is C.c_int32 else "int64_t" for _, c in _lib.HdPrecisionInfo._fields_]
+    assert C.sizeof(_lib.HdPrecisionInfo) == sum(4 if t == "int32_t" else 8 for t, _ in fields) == 40
+    enum = re.search(r"enum \{ (HD_PRECISION_DEFAULT[^}]*)\}", text).group(1)
+    vals = dict((k.strip(), int(v)) for k, v in (e.split("=") for e in enum.split(",")))
+    assert vals == {"HD_PRECISION_DEFAULT": _lib.HD_PRECISION_DEFAULT, "HD_PRECISION_F32_GEMM": _lib.HD_PRECISION_F32_GEMM,
+                    "HD_PRECISION_F32_ALL": _lib.HD_PRECISION_F32_ALL, "HD_PRECISION_SPLIT": _lib.HD_PRECISION_SPLIT}
+
+
+def test_precision_entry_points_reject_null_handles():
+    """The route is part of the C ABI (VERDICT r3 "Next" #1): hd_set_precision / hd_precision_report / hd_precision_reset exist and
+    validate their arguments without a device."""
+    from hudiff_amd import _lib
+    lib = _lib.load()
+    assert lib.hd_set_precision(None, _lib.HD_PRECISION_SPLIT) == _lib.HD_ERR_INVALID
+    r = _lib.HdPrecisionInfo()
+    assert lib.hd_precision_report(None, C.byref(r), C.sizeof(r)) == _lib.HD_ERR_INVALID
+    assert lib.hd_precision_reset(None) == _lib.HD_ERR_INVALID
+    assert lib.hd_sample_tokens(None, None) == _lib.HD_ERR_STATE
+
+
 def test_no_cpu_fallback():
     import hudiff_amd
     from hudiff_amd._lib import HD_ERR_NO_DEVICE, HudiffError

@@ -1,4 +1,4 @@
-"""Both HIP paths -- the fp32 kernels and the split-precision kernels (HUDIFF_X3=1) -- against vectors the REFERENCE's own
+"""The three precision routes of the library (f32_all, f32_gemm, split) against vectors the REFERENCE's own
 classes produced on weights with ugly statistics (oracle/make_golden_adversarial.py; VERDICT r2 "Next" #2): row mean >>
 row std in front of the LayerNorms that are folded into column-centred weights, massive channels, |x| beyond the fp16 range,
 |x| << 2^-3.  The two fixture rows ride in a batch large enough (>= 8192 activation rows) for the big-launch kernels; rows
@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import prec
 from test_adversarial_golden import KINDS, LOGIT_TOL, VARIANTS, load_adv
 
 pytestmark = pytest.mark.gpu
@@ -22,17 +23,11 @@ def hip():
 
 
 def _model(hip, kind, cfg, sd, x3, attn_x3=True):
-    """x3: the split-precision GEMM kernels too (HUDIFF_X3=1); attn_x3=False: HUDIFF_ATTN_X3=0, i.e. every kernel fp32."""
+    """x3: route "split"; otherwise "f32_gemm" (fp32 GEMMs + split attention core) or, attn_x3=False, "f32_all" -- chosen through
+    the interface (precision=), whatever the environment says."""
     cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
-    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
-    os.environ["HUDIFF_X3"] = "1" if x3 else "0"
-    os.environ["HUDIFF_ATTN_X3"] = "1" if attn_x3 else "0"
-    try:
-        m = cls(**cfg)
-        m.load_state_dict(sd)
-    finally:
-        for k, v in prev.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    m = cls(**cfg, precision="split" if x3 else ("f32_gemm" if attn_x3 else "f32_all"))
+    m.load_state_dict(sd)
     return m
 
 
@@ -54,7 +49,7 @@ def _big_batch(kind, z, B):
 @pytest.mark.parametrize("kind", KINDS)
 def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
     z, cfg, sd = load_adv(kind, variant)
-    # f32_all: every kernel fp32; f32: the default product path (fp32 GEMMs + split-precision attention core); x3: HUDIFF_X3=1
+    # f32_all: every kernel fp32; f32: route f32_gemm (fp32 GEMMs + split-precision attention core); x3: route split (the default)
     m = _model(hip, kind, cfg, sd, x3=(path == "x3"), attn_x3=(path != "f32_all"))
     try:
         B = 32 if kind == "ab" else 56                       # 9 312 / 8 512 activation rows: the 128-row-tile kernels
@@ -63,7 +58,7 @@ def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
         assert np.isfinite(logits).all()
         info = m.precision_info()
         if path == "f32_all":
-            assert info == {"split_built": 0, "split_in_use": False, "range_fallbacks": 0}
+            assert (info["split_built"], info["split_in_use"], info["range_fallbacks"], info["lnsync_fallbacks"]) == (0, False, 0, 0)
         else:
             # |x| ~ 1e6 cannot be written as fp16 (hi, lo): the range guard must have repeated the forward on the fp32 kernels
             # (and only there: the other variants stay on the split-precision kernels)
@@ -71,7 +66,7 @@ def test_adversarial_statistics_vs_reference(hip, kind, variant, path):
             # (the default path splits only Q / K / V / P inside the attention core, and the recipe keeps those O(1) even in the
             # `huge` variant -- its guard is exercised by test_attention_core_range_guard below)
             tripped = 1 if (variant == "huge" and path == "x3") else 0
-            assert info["range_fallbacks"] == tripped and info["split_in_use"] == (not tripped)
+            assert info["range_fallbacks"] == tripped and info["split_in_use"] == (not tripped) and info["lnsync_fallbacks"] == 0
         e32 = float(np.abs(logits[:2] - z["logits"]).max())
         e64 = float(np.abs(logits[:2] - z["logits_f64"]).max())
         assert e32 < LOGIT_TOL and e64 < LOGIT_TOL, (kind, variant, path, e32, e64, float(z["reference_f32_vs_f64"]))
@@ -106,11 +101,16 @@ def test_range_guard_inside_a_sampling_session(hip, kind):
         T = np.minimum(fill["T"], 5)
         args = (tokens, region, chain, fill["order"], T)
         got = mx.sample(*args, seed=21, row0=7)
-        assert mx.precision_info() == {"split_built": 3, "split_in_use": False, "range_fallbacks": 1}
+        prec(mx, precision="split", split_built=3, split_in_use=False, range_fallbacks=1, lnsync_fallbacks=0, last_call_repeated=True)
         want = m32.sample(*args, seed=21, row0=7)
         assert np.array_equal(got, want)
         again = mx.sample(*args, seed=21, row0=7)                    # stays on the fp32 kernels: no second fallback
-        assert np.array_equal(again, want) and mx.precision_info()["range_fallbacks"] == 1
+        assert np.array_equal(again, want)
+        prec(mx, range_fallbacks=1, last_call_repeated=False)
+        mx.precision_reset()                                         # hd_precision_reset: back on the split kernels, which trip again
+        prec(mx, split_in_use=True)
+        assert np.array_equal(mx.sample(*args, seed=21, row0=7), want)
+        prec(mx, split_in_use=False, range_fallbacks=2, last_call_repeated=True)
         # split session API (bench.py's shape): begin / restart / run in pieces / end
         mx2 = _model(hip, kind, cfg, sd, x3=True)
         try:
@@ -120,6 +120,34 @@ def test_range_guard_inside_a_sampling_session(hip, kind):
             assert np.array_equal(mx2.sample_end(), want) and mx2.precision_info()["range_fallbacks"] == 1
         finally:
             mx2.close()
+        # bench.py's shape: begin / run / restart / run / ... / end.  A guard that fires in a sample that a restart discards is
+        # still noticed: the handle is on the fp32 kernels for the NEXT sample, and hd_sync notices it as well
+        mx3 = _model(hip, kind, cfg, sd, x3=True)
+        try:
+            mx3.sample_begin(*args, seed=1, row0=7)
+            mx3.sample_run(0, 5)
+            mx3.sample_restart(21)                                   # first sample discarded; its range flag is not
+            prec(mx3, split_in_use=False, range_fallbacks=1)
+            mx3.sample_run(0, 5)
+            mx3.sync()
+            assert np.array_equal(mx3.sample_tokens(), want)         # ran on the fp32 kernels from its first step
+            assert np.array_equal(mx3.sample_end(), want)
+            prec(mx3, range_fallbacks=1, last_call_repeated=False)
+        finally:
+            mx3.close()
+        mx4 = _model(hip, kind, cfg, sd, x3=True)
+        try:
+            mx4.sample_begin(*args, seed=21, row0=7)
+            mx4.sample_run(0, 3)
+            mx4.sync()                                               # notices the flag: the steps so far are invalid ...
+            prec(mx4, split_in_use=False, range_fallbacks=1)
+            with pytest.raises(Exception):
+                mx4.sample_tokens()                                  # ... and are not handed out
+            mx4.sample_run(3, 5)
+            assert np.array_equal(mx4.sample_end(), want)            # ... hd_sample_end repeats all five on the fp32 kernels
+            prec(mx4, range_fallbacks=1, last_call_repeated=True)
+        finally:
+            mx4.close()
     finally:
         mx.close(); m32.close()
 
@@ -141,7 +169,7 @@ def test_attention_core_range_guard(hip, kind):
         B = 32 if kind == "ab" else 56
         fill, tokens, region, chain = _big_batch(kind, z, B)
         a = m(tokens, region, chain, dropout="off")
-        assert m.precision_info() == {"split_built": 2, "split_in_use": False, "range_fallbacks": 1}
+        prec(m, precision="f32_gemm", split_built=2, split_in_use=False, range_fallbacks=1)
         b = m32(tokens, region, chain, dropout="off")
         assert np.isfinite(a).all() and np.array_equal(a, b)
     finally:

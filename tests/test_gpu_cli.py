@@ -74,6 +74,13 @@ def test_antibody_cli_end_to_end(tmp_path):
                      "--batch_size", "3", "--seed", "5", "--device_batch", "4"])
     assert os.path.dirname(out2) != log_dir
     assert open(out2).read() == open(out).read()
+    # --precision picks the library's route (micro shapes run the fp32 small-launch kernels on every route: the same bytes)
+    ckdir3 = tmp_path / "run3" / "checkpoints"
+    ckdir3.mkdir(parents=True)
+    (ckdir3 / "hudiffab.pt").write_bytes((ckdir / "hudiffab.pt").read_bytes())
+    out3 = cli.main(["--ckpt", str(ckdir3 / "hudiffab.pt"), "--data_fpath", str(csv), "--numbered_fpath", str(nb),
+                     "--batch_size", "3", "--seed", "5", "--precision", "f32_all"])
+    assert open(out3).read() == open(out).read()
 
 
 def test_nanobody_cli_end_to_end(tmp_path):

@@ -74,7 +74,7 @@ def test_bench_gather_and_allreduce_through_rccl(tmp_path):
     """bench.py with HUDIFF_BENCH_FORCE_PG=1: the exact collective code of an N > 1 run (nccl init with device_id, barrier,
     dist.gather of the device token tensor, MAX all-reduce of the timings) on one rank."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "24",
-                        "--max-t", "2", "--no-cpu-baseline", "--traffic", "off", "--no-split-line"],
+                        "--max-t", "2", "--no-cpu-baseline", "--traffic", "off"],
                        env=_clean_env(HUDIFF_BENCH_FORCE_PG="1"), cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = _last_json(r.stdout)
@@ -92,6 +92,8 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["process_group"]["world_size"] == 2 and line["config"]["global_rows"] == 48
     assert line["all_tokens_valid"] and line["scaling"] == "weak"
+    pr = line["per_rank_ms_per_step"]                    # a straggler rank is visible (VERDICT r3 "Next" #7)
+    assert len(pr["ranks"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) < 0.05 * line["ms_per_step"] + 50
 
 
 def test_bench_gpus_2_reports_rank_0_counters(tmp_path):
@@ -111,32 +113,46 @@ def test_bench_gpus_2_reports_rank_0_counters(tmp_path):
 def test_default_bench_line_carries_the_measurement_contract(tmp_path):
     """One default-shaped `python bench.py` run (smaller batch, bounded CPU leg): the single JSON line must hold everything the
     measurement contract names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config.workload; `roofline`
-    with bound, achieved, peak, frac, traffic (live PMC), hbm_gbps and mfma_busy; `cpu_baseline` with value / cores / kind / sample; the
-    all-fp32 and split-precision lines with their own rooflines; the HuDiff-Nb secondary line."""
+    with bound, achieved, peak, frac, traffic (live PMC), hbm_gbps and mfma_busy; `cpu_baseline` with value / cores / kind / sample.
+    Round 4 (VERDICT r3 "Next" #2): the top level is the split route and says so (`dtype`, `precision_route`, peak 2500 / 3); the
+    all-fp32 line is sampled as long as the top level and has its own PMC passes; `precision_evidence` compares both routes with a
+    float64 CPU evaluation at three points of the sample and counts token agreement over all timed samples."""
     env = _clean_env()
-    for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3"):       # the DEFAULT line is what is checked, also inside the suite's HUDIFF_X3=1 re-run
+    for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3", "HUDIFF_PRECISION"):       # the DEFAULT line is what is checked, also inside the nested f32_all re-run
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "1", "--warmup", "0",
-                        "--cpu-rows", "2", "--cpu-steps", "2"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "2", "--warmup", "0",
+                        "--cpu-rows", "2", "--cpu-steps", "2", "--evidence-rows", "2"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                      # ONE JSON line
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["unit"] == "sequences/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["unit"] == "sequences/s" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["precision_route"] == "split" and "fp16 hi+lo split, 3 MFMA / product" in d["dtype"] and "< 8192 rows f32" in d["dtype"]
     assert "HuAb348" in d["metric"] and "workload" in d["config"] and d["config"]["rows_per_gpu"] == 64
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"].startswith("TFLOP/s") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["traffic"] and roof["traffic"] > 1e9 and roof["hbm_gbps"] > 100 and 0.05 < roof["mfma_busy"] < 1.0
-    assert roof["route"] == "default" and 157.3 < roof["peak"] < 175 and "frac_vs_fp32_matrix_peak_157.3" in roof
-    assert d["precision_info"] == {"split_built": 2, "split_in_use": True, "range_fallbacks": 0}
+    assert roof["route"] == "split" and abs(roof["peak"] - 2500 / 3) < 0.01
+    pi = d["precision_info"]
+    assert (pi["precision"], pi["split_built"], pi["split_in_use"], pi["range_fallbacks"], pi["lnsync_fallbacks"]) == ("split", 3, True, 0, 0)
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "sequences/s" and cpu["sample"]
-    a, s = d["all_fp32_kernels"], d["split_precision"]
-    assert a["roofline"]["peak"] == 157.3 and a["precision_info"]["split_built"] == 0
-    assert abs(s["roofline"]["peak"] - 2500 / 3) < 0.01 and s["roofline"]["traffic"] and s["precision_info"]["split_built"] == 3
-    assert s["max_abs_dlogit_vs_f32_path"] < 1e-4 and s["rows_with_identical_tokens"].startswith("64 of 64")
+    a = d["all_fp32_kernels"]
+    assert a["steps"] == d["steps"] == 2                       # sampled as long as the top level
+    assert a["roofline"]["peak"] == 157.3 and a["precision_info"]["split_built"] == 0 and a["precision_info"]["precision"] == "f32_all"
+    assert a["roofline"]["traffic"] and a["roofline"]["hbm_gbps"] > 100 and 0.05 < a["roofline"]["mfma_busy"] < 1.0      # its own PMC passes
+    assert a["roofline"].get("clock_power") is None or a["roofline"]["clock_power"]["sclk_mhz_median"] > 500
+    assert a["token_agreement_with_top_level"] == {"rows_identical": 128, "rows_compared": 128, "samples_compared": 2}
+    g = d["f32_gemm_route"]
+    assert g["precision_info"]["precision"] == "f32_gemm" and 157.3 < g["roofline"]["peak"] < 175
+    ev = d["precision_evidence"]
+    assert len(ev["steps_along_the_sample"]) == 3 and ev["steps_along_the_sample"][0] == 0 and ev["bound"] == 1e-4
+    for route in ("split", "f32_all"):
+        e = ev["max_abs_dlogit_vs_float64"][route]
+        assert len(e["per_step"]) == 3 and 0.0 < e["max"] < 1e-4, (route, e)
+    assert ev["token_agreement"]["split vs f32_all"]["rows_identical"] == 128
     nb = d["secondary"]["hudiff_nb_configs3"]
-    assert nb["f32"]["value"] > 0 and nb["split_precision"]["value"] > 0 and "configs[3]" in nb["config"]["workload"]
+    assert nb["split"]["value"] > 0 and nb["f32_all"]["value"] > 0 and "configs[3]" in nb["config"]["workload"]
     assert d["all_tokens_valid"]

@@ -1,9 +1,11 @@
-"""The split-precision GEMM kernels (HUDIFF_X3=1 at hd_finalize: fp32 operands as fp16 hi + lo, three fp16 MFMAs with fp32
-accumulation per product, hd_kernels.hip.h gemm_x3_k) against the float64 oracle, the fp32 HIP path and themselves.
+"""The split-precision route (precision="split", the library default since round 4: fp32 operands as fp16 hi + lo, three fp16
+MFMAs with fp32 accumulation per product, hd_kernels.hip.h gemm_x3_k / attn_x3_k) against the float64 oracle, the all-fp32 route
+(precision="f32_all") and itself.
 
-The fp32 kernels stay the product path; these tests pin what DESIGN.md section 9 claims about the prototype:
-logits within 1e-4 of a float64 evaluation (observed ~1e-6, as close as the fp32 kernels), tokens of complete samples
-equal to the fp32 path's under the same noise, the structural invariances of the sampler (lanes, pruning, sharding)."""
+These tests pin what DESIGN.md section 9 claims about the route: logits within 1e-4 of a float64 evaluation (observed ~1e-6, as
+close as the fp32 kernels), tokens of complete samples equal to the all-fp32 route's under the same noise, the structural
+invariances of the sampler (lanes, pruning, sharding), and the selection interface itself (hd_set_precision / precision=,
+environment overrides of the default only)."""
 import os
 
 import numpy as np
@@ -24,21 +26,13 @@ def hip():
 
 
 def _pair(hip, kind, seed):
+    """(config, weights, all-fp32 handle, split-precision handle): routes chosen through the interface, whatever the environment says"""
     from hudiff_amd import synthetic as S
     cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
     sd = S.random_state_dict(kind, cfg, seed=seed)
     cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
-    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
-    try:
-        os.environ["HUDIFF_X3"] = "0"
-        os.environ["HUDIFF_ATTN_X3"] = "0"               # m32: every kernel fp32 (attn_k)
-        m32 = cls(**cfg); m32.load_state_dict(sd)
-        os.environ["HUDIFF_X3"] = "1"
-        os.environ.pop("HUDIFF_ATTN_X3", None)
-        mx3 = cls(**cfg); mx3.load_state_dict(sd)
-    finally:
-        for k, v in prev.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    m32 = cls(**cfg, precision="f32_all"); m32.load_state_dict(sd)
+    mx3 = cls(**cfg, precision="split"); mx3.load_state_dict(sd)
     return cfg, sd, m32, mx3
 
 
@@ -125,26 +119,70 @@ def test_x3_is_deterministic(hip, kind):
         m32.close(); mx3.close()
 
 
-def test_x3_off_by_default_and_on_small_shapes(hip):
-    """Without HUDIFF_X3 nothing changes; with it, shapes the 128 x 128 x 32 tiles do not cover (the micro goldens) run
-    the fp32 kernels and stay bit-exact against the reference traces."""
-    from conftest import chain_or_none, load_cfg, load_golden, load_weights
-    if os.environ.get("HUDIFF_X3", "0") not in ("", "0"):
-        pytest.skip("suite run with HUDIFF_X3=1 exported: the default-off check does not apply")
+def test_split_is_the_default_and_small_shapes_stay_bit_exact(hip):
+    """A handle built with no precision argument and no environment override takes the split route (VERDICT r3 "Next" #1); shapes the
+    128 x 128 x 32 tiles do not cover (the micro goldens) run the fp32 kernels there and stay bit-exact against the reference traces."""
+    from conftest import chain_or_none, env_forces_route, load_cfg, load_golden, load_weights, prec
     cfg, sd = load_cfg("ab"), load_weights("ab")
-    prev = os.environ.get("HUDIFF_X3")
-    os.environ["HUDIFF_X3"] = "1"
+    m = hip.AntiTFNet(**cfg); m.load_state_dict(sd)
     try:
-        m = hip.AntiTFNet(**cfg); m.load_state_dict(sd)
-    finally:
-        os.environ.pop("HUDIFF_X3", None) if prev is None else os.environ.__setitem__("HUDIFF_X3", prev)
-    try:
+        if not env_forces_route():
+            prec(m, precision="split", split_built=3, split_in_use=True, lnsync_in_use=True, range_fallbacks=0, lnsync_fallbacks=0)
         z = load_golden("micro_ab_sample_finetune.npz")
         B, loc = z["tokens"].shape[0], z["loc"]
         out = m.sample(z["tokens"], z["region"], chain_or_none(z), np.repeat(loc[None], B, 0), np.full(B, len(loc)), q_noise=z["q"])
         assert np.array_equal(out, z["final"])
     finally:
         m.close()
+
+
+def test_precision_selection_interface(hip, monkeypatch):
+    """hd_set_precision / precision=: every route by name; the environment overrides only the DEFAULT (an explicit choice wins);
+    setting it after hd_finalize, or an unknown route, is refused."""
+    import ctypes as C
+    from conftest import load_cfg, load_weights, prec
+    from hudiff_amd import _lib as L
+    cfg, sd = load_cfg("ab"), load_weights("ab")
+
+    def build(precision=None):
+        m = hip.AntiTFNet(**cfg, precision=precision); m.load_state_dict(sd)
+        return m
+
+    for k in ("HUDIFF_PRECISION", "HUDIFF_X3", "HUDIFF_ATTN_X3"):
+        monkeypatch.delenv(k, raising=False)
+    for name, built in (("split", 3), ("f32_gemm", 2), ("f32_all", 0), (None, 3), ("default", 3)):
+        m = build(name)
+        prec(m, precision="split" if name in (None, "default") else name, split_built=built, split_in_use=built != 0)
+        m.close()
+    for env, want in (({"HUDIFF_PRECISION": "f32_all"}, "f32_all"), ({"HUDIFF_PRECISION": "f32_gemm"}, "f32_gemm"), ({"HUDIFF_X3": "0"}, "f32_gemm"),
+                      ({"HUDIFF_X3": "0", "HUDIFF_ATTN_X3": "0"}, "f32_all"), ({"HUDIFF_ATTN_X3": "0"}, "f32_all"), ({"HUDIFF_X3": "1"}, "split")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = build(); prec(m, precision=want); m.close()
+        m = build("split"); prec(m, precision="split"); m.close()            # explicit beats the environment
+        m = build("f32_all"); prec(m, precision="f32_all"); m.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("HUDIFF_PRECISION", "bf16")
+    with pytest.raises(L.HudiffError, match="HUDIFF_PRECISION"):
+        build()
+    monkeypatch.delenv("HUDIFF_PRECISION")
+    with pytest.raises(ValueError):
+        hip.AntiTFNet(**cfg, precision="fp8")
+    m = build()
+    try:
+        lib = L.load()
+        assert lib.hd_set_precision(m._h, L.HD_PRECISION_F32_ALL) == L.HD_ERR_STATE       # after hd_finalize
+        assert lib.hd_set_precision(m._h, 17) in (L.HD_ERR_STATE, L.HD_ERR_INVALID)
+        m.precision_reset()                                                              # nothing to reset: a no-op
+        prec(m, precision="split", split_in_use=True)
+    finally:
+        m.close()
+    m2 = hip.AntiTFNet(**cfg)
+    try:
+        assert L.load().hd_set_precision(m2._h, 17) == L.HD_ERR_INVALID
+    finally:
+        m2.close()
 
 
 def test_x3_feature_masked_epilogues_change_nothing(hip, tmp_path):
@@ -162,7 +200,7 @@ def test_x3_feature_masked_epilogues_change_nothing(hip, tmp_path):
         "b = E.eval_batch('huab348', 64, row0=0)\n"
         "np.save(sys.argv[1], m(b['tokens'], b['region'], b['chain'], dropout='faithful', seed=9, row0=0, step=1))\n")
     out = str(tmp_path / "logits.npy")
-    env = dict(os.environ, HUDIFF_X3="1", HUDIFF_X3_ABL="64")
+    env = dict(os.environ, HUDIFF_PRECISION="split", HUDIFF_X3_ABL="64")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, "-c", code, out], check=True, env=env, cwd=root, timeout=600)
     cfg, sd, m32, mx3 = _pair(hip, "ab", seed=0)
@@ -176,26 +214,19 @@ def test_x3_feature_masked_epilogues_change_nothing(hip, tmp_path):
 
 @pytest.mark.parametrize("kind", ["ab", "nb"])
 def test_split_attention_kernel_inside_the_fp32_path(hip, kind):
-    """The default product path since round 3: fp32 GEMMs with attn_x3_k in place of attn_k for launches >= 8192 rows (fp32 Q|K|V
-    in, fp32 O out); HUDIFF_ATTN_X3=0 at hd_finalize keeps attn_k.  Logits within 1e-4 of the all-fp32 kernels' (observed ~1e-6)
+    """Route f32_gemm (round 3's default): fp32 GEMMs with attn_x3_k in place of attn_k for launches >= 8192 rows (fp32 Q|K|V
+    in, fp32 O out); f32_all keeps attn_k.  Logits within 1e-4 of the all-fp32 kernels' (observed ~1e-6)
     and the same tokens on complete short samples."""
     from hudiff_amd import evalsets as E
     from hudiff_amd import synthetic as S
     cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG)
     sd = S.random_state_dict(kind, cfg, seed=0)
     cls = hip.AntiTFNet if kind == "ab" else hip.NanoAntiTFNet
-    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
-    try:
-        os.environ["HUDIFF_X3"] = "0"
-        os.environ["HUDIFF_ATTN_X3"] = "0"
-        m32 = cls(**cfg); m32.load_state_dict(sd)
-        assert m32.precision_info()["split_built"] == 0
-        os.environ.pop("HUDIFF_ATTN_X3", None)             # the default
-        mat = cls(**cfg); mat.load_state_dict(sd)
-        assert mat.precision_info() == {"split_built": 2, "split_in_use": True, "range_fallbacks": 0}
-    finally:
-        for k, v in prev.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    from conftest import prec
+    m32 = cls(**cfg, precision="f32_all"); m32.load_state_dict(sd)
+    prec(m32, precision="f32_all", split_built=0, split_in_use=False)
+    mat = cls(**cfg, precision="f32_gemm"); mat.load_state_dict(sd)
+    prec(mat, precision="f32_gemm", split_built=2, split_in_use=True, lnsync_in_use=False, range_fallbacks=0)
     try:
         B = 64 if kind == "ab" else 128
         batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
@@ -239,24 +270,27 @@ def test_x3_stress_200_forwards_two_lanes(hip, kind):
             again = mx3(batch["tokens"][:64], batch["region"][:64], np.concatenate([batch["chain"][:64], batch["chain"][B:B + 64]]), **kw) \
                 if kind == "ab" else mx3(batch["tokens"], batch["region"], None, **kw)
             assert np.array_equal(again, lg)
-        assert mx3.precision_info() == {"split_built": 3, "split_in_use": True, "range_fallbacks": 0}
+        from conftest import prec
+        prec(mx3, precision="split", split_built=3, split_in_use=True, lnsync_in_use=True, range_fallbacks=0, lnsync_fallbacks=0)
     finally:
         m32.close(); mx3.close()
 
 
-def test_whole_gpu_suite_with_split_precision_as_process_default(tmp_path):
-    """VERDICT r2 "Next" #3 (iii): every -m gpu test once more in a process that has HUDIFF_X3=1 exported, i.e. with the
-    split-precision kernels as the default of every handle the suite builds (reference traces, adversarial vectors, CLIs,
-    sharding, ...).  Tests that pin the default-off behaviour skip themselves there."""
+def test_whole_gpu_suite_with_all_fp32_as_process_default(tmp_path):
+    """VERDICT r3 "Next" #1 (c): the outer suite runs the library default (split precision); here every -m gpu test runs once more in a
+    process that has HUDIFF_PRECISION=f32_all exported, i.e. with the all-fp32 kernels as the default of every handle the suite
+    builds without naming a route (reference traces, adversarial vectors, CLIs, sharding, ...).  Tests that pin the default skip
+    that part there; tests that name their routes run unchanged."""
     import subprocess
     import sys
-    if os.environ.get("HUDIFF_X3", "0") not in ("", "0"):
-        pytest.skip("already inside the HUDIFF_X3=1 run")
+    from conftest import env_forces_route
+    if env_forces_route():
+        pytest.skip("already inside a run whose environment forces a route")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HUDIFF_X3="1")
+    env = dict(os.environ, HUDIFF_PRECISION="f32_all")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "--deselect", "tests/test_gpu_x3.py::test_whole_gpu_suite_with_split_precision_as_process_default"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+                        "--deselect", "tests/test_gpu_x3.py::test_whole_gpu_suite_with_all_fp32_as_process_default"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=2400)
     tail = r.stdout[-1500:]
     assert r.returncode == 0, tail + r.stderr[-1500:]
     assert " passed" in tail and " failed" not in tail, tail
@@ -271,16 +305,8 @@ def test_attention_blocks_that_would_fill_the_lds_exactly(hip, L):
     from hudiff_amd import synthetic as S
     cfg = dict(S.NB_CONFIG, max_len=L)
     sd = S.random_state_dict("nb", cfg, seed=6)
-    prev = {k: os.environ.get(k) for k in ("HUDIFF_X3", "HUDIFF_ATTN_X3")}
-    try:
-        os.environ["HUDIFF_X3"], os.environ["HUDIFF_ATTN_X3"] = "0", "0"
-        m32 = hip.NanoAntiTFNet(**cfg); m32.load_state_dict(sd)
-        os.environ["HUDIFF_X3"] = "1"
-        os.environ.pop("HUDIFF_ATTN_X3", None)
-        mx3 = hip.NanoAntiTFNet(**cfg); mx3.load_state_dict(sd)
-    finally:
-        for k, v in prev.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    m32 = hip.NanoAntiTFNet(**cfg, precision="f32_all"); m32.load_state_dict(sd)
+    mx3 = hip.NanoAntiTFNet(**cfg, precision="split"); mx3.load_state_dict(sd)
     try:
         B = 128                                              # >= 8192 activation rows, 1 024 attention blocks
         rng = np.random.default_rng(L)

@@ -50,32 +50,28 @@ def test_hip_paths_reproduce_the_reference_trace(kind):
     cls = hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet
     chain = z["chain"] if z["chain"].size else None
     B, Tmax = z["tokens"].shape[0], z["order"].shape[1]
-    prev = os.environ.get("HUDIFF_X3")
-    try:
-        for x3 in ("0", "1"):
-            os.environ["HUDIFF_X3"] = x3
-            m = cls(**cfg); m.load_state_dict(sd)
-            try:
-                # the reference's two rows alone (small-launch fp32 kernels in both modes) ...
-                out = m.sample(z["tokens"], z["region"], chain, z["order"], z["T"], q_noise=z["q"])
-                assert np.array_equal(out, z["final"]), ("rows alone", x3)
-                # ... and inside a launch large enough for the 128-row-tile kernels (fp32 big kernels / split-precision
-                # kernels): filler rows are other real rows with arbitrary noise; rows are independent
-                n = 40 if kind == "ab" else 72
-                fill = E.eval_batch("huab348" if kind == "ab" else "vhh", n - B, row0=100, mode="finetune" if kind == "ab" else "inpaint")
-                Tm = max(Tmax, fill["order"].shape[1])
-                tok = np.concatenate([z["tokens"], fill["tokens"]]); reg = np.concatenate([z["region"], fill["region"]])
-                order = np.zeros((n, Tm), np.int64)
-                order[:B, :Tmax] = z["order"]; order[B:, :fill["order"].shape[1]] = fill["order"]
-                T = np.concatenate([z["T"], fill["T"]])
-                q = np.ones((Tm, n, 22), np.float32)
-                q[:Tmax, :B] = z["q"]
-                q[:, B:] = np.random.default_rng(3).exponential(size=(Tm, n - B, 22)).astype(np.float32)
-                ch = None if chain is None else np.concatenate([chain[:B], fill["chain"][:n - B], chain[B:], fill["chain"][n - B:]])
-                for lanes in (1, 2):
-                    out = m.sample(tok, reg, ch, order, T, q_noise=q, lanes=lanes)
-                    assert np.array_equal(out[:B], z["final"]), ("in a big launch", x3, lanes)
-            finally:
-                m.close()
-    finally:
-        os.environ.pop("HUDIFF_X3", None) if prev is None else os.environ.__setitem__("HUDIFF_X3", prev)
+    for x3 in ("f32_all", "f32_gemm", "split"):               # the three precision routes, chosen through the interface
+        m = cls(**cfg, precision=x3); m.load_state_dict(sd)
+        try:
+            # the reference's two rows alone (small-launch fp32 kernels in both modes) ...
+            out = m.sample(z["tokens"], z["region"], chain, z["order"], z["T"], q_noise=z["q"])
+            assert np.array_equal(out, z["final"]), ("rows alone", x3)
+            # ... and inside a launch large enough for the 128-row-tile kernels (fp32 big kernels / split-precision
+            # kernels): filler rows are other real rows with arbitrary noise; rows are independent
+            n = 40 if kind == "ab" else 72
+            fill = E.eval_batch("huab348" if kind == "ab" else "vhh", n - B, row0=100, mode="finetune" if kind == "ab" else "inpaint")
+            Tm = max(Tmax, fill["order"].shape[1])
+            tok = np.concatenate([z["tokens"], fill["tokens"]]); reg = np.concatenate([z["region"], fill["region"]])
+            order = np.zeros((n, Tm), np.int64)
+            order[:B, :Tmax] = z["order"]; order[B:, :fill["order"].shape[1]] = fill["order"]
+            T = np.concatenate([z["T"], fill["T"]])
+            q = np.ones((Tm, n, 22), np.float32)
+            q[:Tmax, :B] = z["q"]
+            q[:, B:] = np.random.default_rng(3).exponential(size=(Tm, n - B, 22)).astype(np.float32)
+            ch = None if chain is None else np.concatenate([chain[:B], fill["chain"][:n - B], chain[B:], fill["chain"][n - B:]])
+            for lanes in (1, 2):
+                out = m.sample(tok, reg, ch, order, T, q_noise=q, lanes=lanes)
+                assert np.array_equal(out[:B], z["final"]), ("in a big launch", x3, lanes)
+        finally:
+            m.close()
+
