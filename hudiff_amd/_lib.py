@@ -26,7 +26,7 @@ EXPORTS = [
     "hd_device_count", "hd_create", "hd_load_tensor", "hd_finalize", "hd_destroy", "hd_last_error",
     "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
     "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read", "hd_precision_info",
-    "hd_set_precision", "hd_precision_report", "hd_precision_reset", "hd_sample_tokens",
+    "hd_set_precision", "hd_precision_report", "hd_precision_reset", "hd_sample_tokens", "hd_debug_fail_next_lnsync",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     lib.hd_set_precision.argtypes = [vp, C.c_int32]
     lib.hd_precision_report.argtypes = [vp, P(HdPrecisionInfo), C.c_size_t]
     lib.hd_precision_reset.argtypes = [vp]
+    lib.hd_debug_fail_next_lnsync.argtypes = [vp]
     lib.hd_debug_stop_after.argtypes = [vp, C.c_int32]
     lib.hd_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64]
     _lib = lib

@@ -181,6 +181,7 @@ struct HdModel {
     bool s_dirty = false;                            // a guard fired in the steps run since the last begin / restart: their tokens are invalid
     int last_steps = 0; bool timed = false;
     int debug_stop_after = 0;     // 0 = run everything (hd_debug_stop_after)
+    bool debug_lnsync_fail = false;   // hd_debug_fail_next_lnsync: ln_sync meetings of the next call give up after one poll
 };
 
 // the lane (stream + workspace + graph) the helper functions currently address
@@ -911,7 +912,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         GemmP q = p;
         q.sg = run;
         static const int abl = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e ? atoi(e) : 0; }();
-        q.x3_abl = abl;
+        q.x3_abl = abl | ((m->debug_lnsync_fail && q.ln_sync) ? 128 : 0);
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
         // tile shape / pipeline depth, by measurement: 256 x 256 tiles (two stages, one 8-wave block per CU)
         // for the widest output (Q|K|V, N = 1536: 621 vs 650 us), two stages of 128 x 128 tiles (two blocks per CU) elsewhere; three
@@ -1333,6 +1334,7 @@ static void suspend_lnsync(HdModel* m, uint32_t bits) {
                 (bits & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
     m->lnsync_level = 0;
     m->lnsync_fallbacks += 1;
+    m->debug_lnsync_fail = false;
     for (auto& ln : m->lane) ln.drop_graphs();      // captured with the meeting epilogues
 }
 
@@ -1754,6 +1756,13 @@ extern "C" HdStatus hd_last_run_ms(HdModel* m, float* ms, int32_t* steps) {
 extern "C" HdStatus hd_debug_stop_after(HdModel* m, int32_t stage) {
     if (!m) return fail(HD_ERR_INVALID, "hd_debug_stop_after: null model");
     m->debug_stop_after = stage;   // 1: after the token encoder (+static add), 2+n: before attention block n
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_debug_fail_next_lnsync(HdModel* m) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_debug_fail_next_lnsync: null model");
+    m->debug_lnsync_fail = true;   // the ln_sync meetings of the kernels launched / captured next give up after one poll
+    for (auto& ln : m->lane) ln.drop_graphs();
     return HD_OK;
 }
 

@@ -179,13 +179,17 @@ struct GemmP {
     // split-precision variant (gemm_x3_k): W as pre-tiled (hi, lo) fp16 planes scaled by a power of two, per segment at
     // + seg * wx_stride halfs; acc_scale = 2^-(weight shift + activation shift) undoes the scaling in the epilogue
     const uint16_t* Wx; long wx_stride; float acc_scale;
-    // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as K fp16 high parts
-    // followed by K fp16 low parts (x ~= hi + lo).  gemm_x3_k reads its A operand in this form (written by its producer:
-    // ln_apply_k, attn_k, or a GEMM epilogue with c_split / C2), so its K loop carries no conversion.
+    // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as, per group of 32 columns, 32 fp16
+    // high parts followed by 32 fp16 low parts (x ~= hi + lo; x16_hi()).  A (row, k tile of 32) is then ONE 128-byte cache line:
+    // rounds 2-3 kept all K high parts, then all K low parts, so that every DMA request of a k tile touched two half lines per row
+    // and the vector L1 -- far smaller than the A panels in flight -- fetched each line twice.  gemm_x3_k reads its A operand in this
+    // form (written by its producer: ln_apply_k, attn_k / attn_x3_k, or a GEMM epilogue with c_split / C2 / ln_sync), so its K loop
+    // carries no conversion.
     int st_nt;                        // fp32 kernels: epilogue stores carry the non-temporal policy (gemm_x3_k always stores non-temporally:
                                       // streamed outputs then do not displace operand lines in L2)
     int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tiles,
-                                      // 3 = neither (epilogue only), 4 = one LDS fragment read per k step
+                                      // 3 = neither (epilogue only), 4 = one LDS fragment read per k step; bit 7 (128): ln_sync meetings
+                                      // give up after one poll (hd_debug_fail_next_lnsync: exercises the ln_sync guard)
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
     float* C2;                        // epilogue: additional split copy of the output rows, row stride N (may be null)
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
@@ -276,6 +280,10 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 #define HD_SPLIT4_MODE 0
 #endif
 typedef _Float16 hd_f16x4 __attribute__((ext_vector_type(4)));
+// X16 row format (GemmP): half index of the HIGH part of column c; its low part sits 32 halfs further.  Columns c .. c + 3 of a
+// float4 (c % 4 == 0) stay contiguous.
+__host__ __device__ __forceinline__ constexpr int x16_hi(int c) { return ((c >> 5) << 6) | (c & 31); }
+constexpr int X16_LO = 32;
 __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     hh = __builtin_convertvector(v, hd_f16x4);
@@ -383,13 +391,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 if ((HD_GUARD_MASK & 1) && valid) vmax = absmax4(vmax, v);
                 float* base = c_split ? p.C : p.C2;
                 const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(base + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
-                const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
+                const uint32_t s_vo = (uint32_t)(e_r * N * 4 + x16_hi(colc) * 2);
                 if ((F & EPI_X3) || p.st_nt) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)X16_LO * 2 : BUF_OFF), 0, 2);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)X16_LO * 2 : BUF_OFF), 0, 0);
                 }
             }
     };
@@ -532,7 +540,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 const int xcc = __builtin_amdgcn_s_getreg(6164) & 15;    // HW_REG_XCC_ID[3:0]
                 __hip_atomic_fetch_or(ctr + 2, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int budget = 1 << 20;                                    // ~1 s of polling: far beyond any launch; then give up loudly
+                // ~1 s of polling: far beyond any launch; then give up loudly (the host repeats the call with ln_apply_k passes).
+                // Probe bit 7 of x3_abl (hd_debug_fail_next_lnsync, tests only): a budget of one poll, so that the guard's path runs
+                int budget = (p.x3_abl & 128) ? 1 : (1 << 20);
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.tiles_n && --budget > 0)
                     __builtin_amdgcn_s_sleep(1);
                 const int seen = __hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -610,9 +620,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                     split4(w, hh, ll);
                     if (valid) smax = absmax4(smax, w);
                     const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc(p.S + (long)(rbase + g0) * N, 0, BUF_MAX, 0x00020000);
-                    const uint32_t s_vo = (uint32_t)(e_r * N * 4 + colc * 2);
+                    const uint32_t s_vo = (uint32_t)(e_r * N * 4 + x16_hi(colc) * 2);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ss, (int)(valid ? s_vo : BUF_OFF), 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)N * 2 : BUF_OFF), 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ss, (int)(valid ? s_vo + (uint32_t)X16_LO * 2 : BUF_OFF), 0, 2);
                 }
             }
             raise_range_flag(p.rs, smax);
@@ -1035,6 +1045,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
     constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
     constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
+    // LDS image of a stage: A as BM rows of 128 B = [hi 32 halfs | lo 32 halfs] (the X16 row format: one cache line per row and
+    // k tile), its eight 16-byte chunks XOR-swizzled by (row >> 1) & 7; W as two planes (hi, lo) of BN rows x 64 B, chunks
+    // swizzled by (row >> 2) & 3 (baked into the weight images)
     static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0, "tile / wave split");
     static_assert(lds_fill_ok(SM_FLOATS * 4, NT), "co-resident blocks of this kernel would fill the CU's LDS (see LDS co-residency rule)");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
@@ -1070,9 +1083,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         }
         // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
     }
-    // DMA pieces of 1 KiB = 16 rows x 64 B of one plane; lane l lands at piece base + 16 l = row l >> 2, slot l & 3, and
-    // fetches chunk slot ^ swizzle(row).  A rows: 4 lda bytes per row = lda hi halfs then lda lo halfs.  Rows past the
-    // segment end and conv padding get an offset the descriptor's range check rejects: the DMA writes zeros.
+    // A pieces of 1 KiB = 8 rows x 128 B: lane l lands at piece base + 16 l = row l >> 3, slot l & 7, and fetches chunk
+    // slot ^ swizzle(row) of the row's 128-byte (hi | lo) group of this k tile -- one full cache line per row.  W pieces of 1 KiB =
+    // 16 rows x 64 B of one plane, copied linearly.  Rows past the segment end and conv padding get an offset the descriptor's
+    // range check rejects: the DMA writes zeros.
     constexpr uint32_t BUF_OOB = 0x80000000u;
     int a_pos[A_PIECES];
     long a_row[A_PIECES];
@@ -1080,13 +1094,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
     uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
-        const int piece = NW * i + wave;                                 // plane piece / (BM / 16), rows 16 (piece % (BM / 16)) ..
-        const int r = 16 * (piece % (BM / 16)) + (lane >> 2);
+        const int piece = NW * i + wave;                                 // rows 8 piece ..
+        const int r = 8 * piece + (lane >> 3);
         const int lrow = m0 + r;
         a_ok[i] = lrow < seg_rows;
         a_pos[i] = CONV ? (lrow % Lc) : 0;
         a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
-        a_in[i] = (uint32_t)((piece / (BM / 16)) * p.lda * 2 + (((lane & 3) ^ ((r >> 2) & 3)) << 4));     // plane + swizzled chunk
+        a_in[i] = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);      // swizzled chunk of the 128-byte group
         a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
     }
 #pragma unroll
@@ -1114,7 +1128,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
         char* dst = St + st * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], kk0 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], kk0 * 4, 0, 0);
 #pragma unroll
         for (int i = 0; i < W_PIECES; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(dst + A_BYTES + (NW * i + wave) * 1024), 16, (int)w_vo[i],
@@ -1129,19 +1143,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
-    // chunk ^ ((r >> 2) & 3); the wave part and 32 t do not touch bits 2..3 of r
-    const int fsw = (lane >> 2) & 3, fg = lane >> 5;
+    // W fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
+    // chunk ^ ((r >> 2) & 3) of its 64-byte plane row; A fragment: high-part chunk 2 ks + g (low part: + 4) at slot
+    // chunk ^ ((r >> 1) & 7) of the 128-byte row.  The wave part and 32 t do not touch bits 1..3 of r.
+    const int fsw = (lane >> 2) & 3, fg = lane >> 5, asw = (lane >> 1) & 7;
     const int foff0 = (lane & 31) * 64 + (((0 + fg) ^ fsw) << 4), foff1 = (lane & 31) * 64 + (((2 + fg) ^ fsw) << 4);
+    const int aoff0 = (lane & 31) * 128 + (((0 + fg) ^ asw) << 4), aoff1 = (lane & 31) * 128 + (((2 + fg) ^ asw) << 4);
     auto mma = [&](int st) {
-        const char* At = St + st * STAGE_BYTES + wm * WTM * 64;
+        const char* At = St + st * STAGE_BYTES + wm * WTM * 128;
         const char* Wt = St + st * STAGE_BYTES + A_BYTES + wn * WTN * 64;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const int o = ks ? foff1 : foff0;
+            const int o = ks ? foff1 : foff0, oa = ks ? aoff1 : aoff0;
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
             if (abl_mode == 4) {                       // probe: one fragment read per k step instead of 2 (TM + TN)
-                const f16x8 f = *reinterpret_cast<const f16x8*>(At + o);
+                const f16x8 f = *reinterpret_cast<const f16x8*>(At + oa);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) { ah[i] = f; al[i] = f; }
 #pragma unroll
@@ -1149,8 +1165,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 
             } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(At + o + 32 * 64 * i);
-                al[i] = *reinterpret_cast<const f16x8*>(At + A_BYTES / 2 + o + 32 * 64 * i);
+                ah[i] = *reinterpret_cast<const f16x8*>(At + oa + 32 * 128 * i);
+                al[i] = *reinterpret_cast<const f16x8*>(At + (oa ^ 64) + 32 * 128 * i);      // low parts: chunk + 4
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -1294,8 +1310,8 @@ __global__ void __launch_bounds__(256) ln_apply_k(const float2* __restrict__ par
                 f16x4 hh, ll;
                 split4(w, hh, ll);
                 if (HD_GUARD_MASK & 2) vmax = absmax4(vmax, w);
-                *reinterpret_cast<f16x4*>(yh + c) = hh;
-                *reinterpret_cast<f16x4*>(yh + C + c) = ll;
+                *reinterpret_cast<f16x4*>(yh + x16_hi(c)) = hh;
+                *reinterpret_cast<f16x4*>(yh + x16_hi(c) + X16_LO) = ll;
             }
         }
         raise_range_flag(rs, vmax);
@@ -1674,8 +1690,8 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                     split4(o, hh, ll);
                     if (HD_GUARD_MASK & 4) vmax = absmax4(vmax, o);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
-                    *reinterpret_cast<f16x4*>(orow + col) = hh;
-                    *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
+                    *reinterpret_cast<f16x4*>(orow + x16_hi(col)) = hh;
+                    *reinterpret_cast<f16x4*>(orow + x16_hi(col) + X16_LO) = ll;
                 } else {
                     *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
                 }
@@ -1960,8 +1976,8 @@ __global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_
                     f16x4 hh, ll;
                     split4(o, hh, ll);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
-                    *reinterpret_cast<f16x4*>(orow + col) = hh;
-                    *reinterpret_cast<f16x4*>(orow + ldo + col) = ll;
+                    *reinterpret_cast<f16x4*>(orow + x16_hi(col)) = hh;
+                    *reinterpret_cast<f16x4*>(orow + x16_hi(col) + X16_LO) = ll;
                 } else {
                     *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
                 }

@@ -274,6 +274,9 @@ class _Denoiser:
         """hd_precision_reset: back on the configured route after a guard switched kernels off."""
         L.check(self._lib.hd_precision_reset(self._h))
 
+    def debug_fail_next_lnsync(self):
+        L.check(self._lib.hd_debug_fail_next_lnsync(self._h))
+
     def debug_stop_after(self, stage):
         L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
 

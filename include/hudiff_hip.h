@@ -221,6 +221,9 @@ HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_cou
  * attention block n); hd_debug_read copies an activation buffer ("X","FEAT","Y","POS","EXTRA","AT") of
  * the last call back as [B, L, width]. */
 HdStatus hd_debug_stop_after(HdModel* m, int32_t stage);
+/* Makes the ln_sync meetings of the next call give up after one poll, so that the ln_sync guard (see "precision routes") fires and
+ * its repeat path can be tested; cleared when the guard has fired. */
+HdStatus hd_debug_fail_next_lnsync(HdModel* m);
 HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats);
 
 #ifdef __cplusplus

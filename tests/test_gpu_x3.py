@@ -276,6 +276,44 @@ def test_x3_stress_200_forwards_two_lanes(hip, kind):
         m32.close(); mx3.close()
 
 
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_lnsync_guard_repeats_the_call_with_layernorm_passes(hip, kind):
+    """VERDICT r3 "Next" #1 (b): a failed ln_sync meeting is no error.  hd_debug_fail_next_lnsync makes the meetings of the next call
+    give up after one poll (most blocks then leave before their M tile's other N tiles have arrived): the guard flag is raised, the
+    call is repeated with ln_apply_k passes, counted in lnsync_fallbacks, and the handle keeps those until hd_precision_reset --
+    in hd_forward and inside a sampling session (graph replays, two lanes), with the tokens of an undisturbed handle."""
+    from conftest import prec
+    from hudiff_amd import evalsets as E
+    cfg, sd, m32, mx3 = _pair(hip, kind, seed=0)
+    try:
+        B = 64 if kind == "ab" else 128
+        batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
+        kw = dict(dropout="faithful", seed=9, row0=0, step=1)
+        clean = mx3(batch["tokens"], batch["region"], batch["chain"], **kw)
+        prec(mx3, lnsync_in_use=True, lnsync_fallbacks=0, last_call_repeated=False)
+        mx3.debug_fail_next_lnsync()
+        got = mx3(batch["tokens"], batch["region"], batch["chain"], **kw)
+        prec(mx3, split_in_use=True, lnsync_in_use=False, lnsync_fallbacks=1, range_fallbacks=0, last_call_repeated=True)
+        assert np.isfinite(got).all() and np.abs(got - clean).max() < 2e-5           # the same arithmetic, LayerNorm in a separate pass
+        again = mx3(batch["tokens"], batch["region"], batch["chain"], **kw)
+        assert np.array_equal(again, got)
+        prec(mx3, lnsync_fallbacks=1, last_call_repeated=False)
+        mx3.precision_reset()
+        prec(mx3, lnsync_in_use=True)
+        assert np.array_equal(mx3(batch["tokens"], batch["region"], batch["chain"], **kw), clean)
+        # inside a session: begin / run / end with graph replays on two lanes
+        Bs = 128 if kind == "ab" else 160
+        big = E.eval_batch("huab348" if kind == "ab" else "vhh", Bs, row0=0)
+        args = (big["tokens"], big["region"], big["chain"], big["order"], np.minimum(big["T"], 4))
+        want = mx3.sample(*args, seed=13, row0=0)
+        assert np.array_equal(want, m32.sample(*args, seed=13, row0=0))
+        mx3.debug_fail_next_lnsync()
+        assert np.array_equal(mx3.sample(*args, seed=13, row0=0), want)
+        prec(mx3, split_in_use=True, lnsync_in_use=False, lnsync_fallbacks=2, range_fallbacks=0, last_call_repeated=True)
+    finally:
+        m32.close(); mx3.close()
+
+
 def test_whole_gpu_suite_with_all_fp32_as_process_default(tmp_path):
     """VERDICT r3 "Next" #1 (c): the outer suite runs the library default (split precision); here every -m gpu test runs once more in a
     process that has HUDIFF_PRECISION=f32_all exported, i.e. with the all-fp32 kernels as the default of every handle the suite
