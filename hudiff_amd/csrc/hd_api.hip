@@ -94,6 +94,19 @@ struct Workspace {
 };
 
 constexpr int HD_MAX_LANES = 4;
+// Launches of at least this many activation rows take the big-launch kernels (128-row tiles, split precision where the route has
+// it); smaller ones the generic 32 x 128 fp32 kernels.  HUDIFF_BIG_ROWS: tuning aid (default 8192).
+static long big_rows() {
+    static long n = [] { const char* e = getenv("HUDIFF_BIG_ROWS"); long v = e ? atol(e) : 8192; return v < 1 ? 1 : v; }();
+    return n;
+}
+// Split-precision launches need fewer rows to pay: the 128 x 128 split kernels beat the generic fp32 ones from ~1 000 activation rows on
+// (round 4 sweep, profiles/r04/small_batch_sweep.txt: B = 16 antibodies 25.2 -> 35.6 sequences/s, B = 24 29.6 -> 47.2, B = 8 17.6 ->
+// 20.0; the fp32 big-launch kernels gain nothing below 8192 rows).  HUDIFF_X3_ROWS: tuning aid (default 1024).
+static long x3_rows() {
+    static long n = [] { const char* e = getenv("HUDIFF_X3_ROWS"); long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
+    return n;
+}
 static int lanes_default() {
     static int n = [] { const char* e = getenv("HUDIFF_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > HD_MAX_LANES ? HD_MAX_LANES : v); }();
     return n;
@@ -799,7 +812,7 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
 // caller BEFORE it asks the producer for split rows -- x3_use() holds every condition launch_gemm checks again.
 static bool x3_use(const HdModel* m, const Segs& sg, const X3W& x) {
     const long rows = (long)sg.B * sg.L, widest = 3L * m->A > m->D ? 3L * m->A : m->D;       // 32-bit byte offsets in every operand
-    return m->x3 && !m->x3_suspended && x.w && rows >= 8192 && rows * widest * 4 < (1L << 31);
+    return m->x3 && !m->x3_suspended && x.w && rows >= x3_rows() && rows * widest * 4 < (1L << 31);
 }
 static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
@@ -880,7 +893,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     Workspace& ws = cur(m).ws;
     hipStream_t st = cur(m).stream;
     const long rows = (long)p.sg.B * p.sg.L;
-    const bool big = rows >= 8192;
+    const bool big = rows >= big_rows() || p.Wx != nullptr;      // (split-precision launches: x3_use() decided)
     const int pw = big ? 64 : 32;
     p.part_rows = rows;
     // non-temporal epilogue stores: +0.9 % on the split-precision sample (3 x 3 interleaved runs; gemm_x3_k always uses them),
@@ -1122,7 +1135,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     // ... and address QKV with 32-bit byte offsets
     // m->attn_x3 (default; HUDIFF_ATTN_X3=0 at hd_finalize turns it off): the split-precision attention kernel inside the fp32 path as
     // well (fp32 Q|K|V in, fp32 O out)
-    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= 8192)) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= big_rows())) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
     static const bool ax_w8 = [] { const char* e = getenv("HUDIFF_ATTN_WAVES"); return e && atoi(e) == 8; }();

@@ -150,11 +150,12 @@ __device__ __forceinline__ float dpp_f(float v) {
 }
 template <int N>
 __device__ __forceinline__ float group_sum(float v) {
-    static_assert(N == 8 || N == 16, "group of 8 or 16 lanes");
+    static_assert(N == 8 || N == 16 || N == 32, "group of 8, 16 or 32 lanes");
     v += dpp_f<0xB1>(v);       // quad_perm(1,0,3,2)
     v += dpp_f<0x4E>(v);       // quad_perm(2,3,0,1)
     v += dpp_f<0x141>(v);      // row_half_mirror
-    if (N == 16) v += dpp_f<0x140>(v);   // row_mirror
+    if (N >= 16) v += dpp_f<0x140>(v);   // row_mirror
+    if (N == 32) v += __shfl_xor(v, 16); // the neighbouring DPP row (wave tiles 128 columns wide)
     return v;
 }
 

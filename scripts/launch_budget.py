@@ -6,13 +6,16 @@ written by scripts/x3_seq.sh (rocpd_summary.py --sequence):
     python scripts/launch_budget.py gpurun_out/seq_f32/sequence.txt default     > profiles/r03/ab256_launch_budget.txt
     python scripts/launch_budget.py gpurun_out/seq_allf32/sequence.txt allfp32  > profiles/r03/ab256_allfp32_launch_budget.txt
 
-Routes: `default` = fp32 MFMA GEMMs + split-precision attention core (priced at 2500 / 3), `allfp32` = HUDIFF_ATTN_X3=0, `x3` = HUDIFF_X3=1.
+Routes (precision routes of include/hudiff_hip.h): `default` = f32_gemm (fp32 MFMA GEMMs + split-precision attention core, priced at 2500 / 3),
+`allfp32` = f32_all, `x3` = split (the library default since round 4).
 
 Every GEMM / attention launch is named by its place in the network (the launch order is fixed), priced with its algorithmic
 FLOPs (2 M N K taps; attention 4 L^2 x 64 per head) and with the FEWEST HBM bytes its operands allow (activation operand read
 once, every output written once, residual read once; weights stay in L2 / Infinity Cache), and compared with both ceilings of
-its route: the matrix peak (fp32 MFMA 157.3 TFLOP/s; split route 2500 / 3) and ~4.5 TB/s of achievable HBM streaming.  `floor`
-is max(FLOPs / peak, bytes / 4.5 TB/s): what a perfect kernel of this shape would take; the last line sums them.
+its route: the matrix peak (fp32 MFMA 157.3 TFLOP/s; split route 2500 / 3) and the HBM streaming rate the guide measures as
+achievable, 6.29 TB/s of the 8.0 TB/s spec (MI355X_MICROARCH.md "HBM"; rounds 2-3 priced 4.5 TB/s here, which made every
+HBM-bound launch look closer to its floor than it is: VERDICT r3).  `floor` is max(FLOPs / peak, bytes / 6.29 TB/s): what a perfect
+kernel of this shape would take; the fraction of the 8.0 TB/s spec is printed beside it; the last line sums the floors.
 """
 import re
 import sys
@@ -20,7 +23,8 @@ import sys
 M = 256 * 291                      # activation rows of the batch
 L, H = 291, 8
 d, dh, D, Dh, A, Fd = 256, 128, 768, 384, 512, 256
-HBM = 4.5e12                       # achievable streaming rate (ln_apply_k / fill kernels reach 4.6-4.9 TB/s)
+HBM = 6.29e12                      # achievable HBM streaming rate of the guide (MI355X_MICROARCH.md); HBM_SPEC is the 8.0 TB/s figure
+HBM_SPEC = 8.0e12
 
 
 def gemm(K, N, taps=1):
@@ -75,7 +79,7 @@ def main():
     total = sum(r[0] for r in rows)
     print(f"one denoiser step, HuDiff-Ab, 256 rows, one lane, route {route}: {total / 1e3:.2f} ms of kernels in {len(rows)} dispatches; "
           f"GEMMs + attention cores {big / 1e3:.2f} ms, everything else {(total - big) / 1e3:.2f} ms")
-    print(f"{'launch':38s} {'n':>3s} {'avg us':>8s} {'GFLOP':>7s} {'TFLOP/s':>8s} {'of peak':>8s} {'min MB':>7s} {'TB/s':>6s} {'of 4.5':>7s} {'bound':>6s} {'floor us':>9s}")
+    print(f"{'launch':38s} {'n':>3s} {'avg us':>8s} {'GFLOP':>7s} {'TFLOP/s':>8s} {'of peak':>8s} {'min MB':>7s} {'TB/s':>6s} {'of 6.29':>7s} {'of 8.0':>7s} {'bound':>6s} {'floor us':>9s}")
     floor_sum = 0.0
     for nm in order:
         n, us, fl, by = agg[nm]
@@ -85,7 +89,7 @@ def main():
         f_m, f_h = fl / pk, by / HBM
         floor = max(f_m, f_h)
         floor_sum += floor * n
-        print(f"{nm:38s} {n:3d} {us / n:8.1f} {fl / 1e9:7.1f} {tf / 1e12:8.1f} {tf / pk:8.3f} {by / 1e6:7.0f} {bw / 1e12:6.2f} {bw / HBM:7.3f} "
+        print(f"{nm:38s} {n:3d} {us / n:8.1f} {fl / 1e9:7.1f} {tf / 1e12:8.1f} {tf / pk:8.3f} {by / 1e6:7.0f} {bw / 1e12:6.2f} {bw / HBM:7.3f} {bw / HBM_SPEC:7.3f} "
               f"{'MFMA' if f_m >= f_h else 'HBM':>6s} {floor * 1e6:9.1f}")
     print(f"sum of floors of the launches above: {floor_sum * 1e3:.2f} ms against {big / 1e3:.2f} ms measured "
           f"({floor_sum * 1e3 / (big / 1e3):.2f} of it); with the other kernels unchanged the step would take "

@@ -82,6 +82,241 @@ static float run(GemmP q, int abl, double seconds, const char* tag) {
     return ms_total / iters;
 }
 
+namespace hd {
+// ------------------------------------------------------------------------------------------------
+// gemm_x3h_k: the split-precision GEMM with 16-deep k tiles ("h" = half k tile), round 4.
+// MEASURED AND NOT ADOPTED (round 4): kept here, in the probe, as the record of the experiment.  Bit-identical
+// to gemm_x3_k on the Q|K|V shape, but 432 vs 404 us per isolated launch: the loop's operand DMA is bound by the L2 -> LDS fabric
+// (~16-19 TB/s chip-wide: 256 x 256 tiles move 2.8 GB per launch in 168 us, 256 x 128 tiles 4.2 GB in 271 us), so the 1.5 x bytes of
+// the smaller tile cost the loop more (350 -> 378 us) than the overlapped epilogue returns (87 us alone, 53 us exposed).
+// gemm_x3_k's widest launch (Q|K|V, 256 x 256 tiles) owns a CU alone: nothing computes while its epilogue drains 458 MB of
+// stores (VERDICT r3 "Next" #3 i).  A k tile of 16 makes a stage of a 256 x 128 tile 24 KB (A 256 rows x 64 B, W 2 planes x 128
+// rows x 32 B), so that two or three stages fit TWICE per CU beside the epilogue's staging: one block's epilogue runs under the
+// other's K loop, at 0.75 of the operand bytes per flop of 128 x 128 tiles.  Same operand formats as gemm_x3_k: A in X16 rows
+// (per 32 columns 32 high parts then 32 low parts: a 16-column k tile takes 32 B of each), W from the [128][32] tile images
+// (half of every 64-byte row).  LDS images: A rows of 64 B = [hi k 0-7 | hi k 8-15 | lo k 0-7 | lo k 8-15], chunks swizzled by
+// (row >> 2) & 3; W planes of 32-byte rows, chunks swizzled by (row >> 3) & 1 -- conflict-free ds_read_b128 fragments.
+// The epilogue is gemm_x3_k's.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
+__global__ void __launch_bounds__(64 * WM * WN, 2) gemm_x3h_k(const GemmP p) {
+    constexpr int BK = 16, NW = WM * WN, NT = 64 * NW;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int ES = WTN + 4;
+    constexpr int EPI_FLOATS = NW * 32 * ES, PART_FLOATS = NW * WTM * 2;
+    constexpr int A_BYTES = BM * 64, W_PLANE = BN * 32, W_BYTES = 2 * W_PLANE;
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int LOOP_FLOATS = NS * STAGE_BYTES / 4;
+    constexpr int WORK_FLOATS = LOOP_FLOATS > EPI_FLOATS + PART_FLOATS ? LOOP_FLOATS : EPI_FLOATS + PART_FLOATS;
+    constexpr int SM_FLOATS = WORK_FLOATS + 2 * BM;
+    constexpr int A_PIECES = A_BYTES / 1024 / NW, W_PIECES = W_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and tile
+    static_assert(A_BYTES / 1024 % NW == 0 && W_BYTES / 1024 % NW == 0 && BN % X3_BN == 0 && W_PLANE % 1024 == 0, "tile / wave split");
+    static_assert(lds_fill_ok(SM_FLOATS * 4, NT), "co-resident blocks of this kernel would fill the CU's LDS (see LDS co-residency rule)");
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A rows, W hi plane, W lo plane
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bx, by, seg = 0;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
+        by = slot % p.tiles_n;
+        bx = (slot / p.tiles_n) * 8 + xcd;
+        if (bx >= p.tiles_m) return;
+    }
+    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+    const int abl_mode = p.x3_abl & 7;                 // probes only (scripts/x3_probe.hip); bit 3 = no epilogue, bit 5 = no stores
+    const int Lc = p.sg.len[seg];
+    const int seg_rows = p.sg.B * Lc;
+    const int rbase = p.sg.base[seg];
+    const int m0 = bx * BM, n0 = by * BN;
+    const int Kc = p.Kc;
+    const int nkt_tap = Kc / BK;                       // Kc % 32 == 0: an even number of half tiles per tap
+    const int nkt = nkt_tap * p.taps;
+    const int nkt32 = nkt / 2;                         // 32-deep tiles of the weight image
+    const int half = (p.taps - 1) / 2;
+    const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt32 * X3_TILE_HALFS;
+
+    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
+        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += NT) {
+            const int lrow = m0 + r;
+            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+        }
+    }
+    // A pieces of 1 KiB = 16 rows x 64 B: lane l lands at row l >> 2, slot l & 3 and fetches logical chunk c = slot ^ swizzle(row):
+    // c < 2 the high parts k 8c .. 8c+7 of this half tile, c >= 2 the low parts -- 32 B of each half of the row's 128-byte group.
+    // W pieces of 1 KiB = 32 rows x 32 B of one plane: lane l lands at row l >> 1, slot l & 1 and fetches the image's chunk
+    // 2 (kt & 1) + (slot ^ swizzle(row)), which the image keeps at position chunk ^ ((row >> 2) & 3): the lane offset of an odd
+    // half tile is that of an even one with bit 5 flipped.
+    constexpr uint32_t BUF_OOB = 0x80000000u;
+    int a_pos[A_PIECES];
+    long a_row[A_PIECES];
+    bool a_ok[A_PIECES];
+    uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int piece = NW * i + wave;
+        const int r = 16 * piece + (lane >> 2);
+        const int lrow = m0 + r;
+        a_ok[i] = lrow < seg_rows;
+        a_pos[i] = CONV ? (lrow % Lc) : 0;
+        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        a_in[i] = (uint32_t)((c & 1) * 16 + (c >> 1) * 64);
+        a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) {
+        const int piece = NW * i + wave;                                 // LDS image: hi plane of all BN rows, then lo plane
+        const int plane = piece / (W_PLANE / 1024), rg = piece % (W_PLANE / 1024);      // row group of 32 rows
+        const int r = 32 * rg + (lane >> 1);                             // row of the block's BN columns
+        const int t128 = r / X3_BN, r128 = r % X3_BN;
+        const int c = (lane & 1) ^ ((r >> 3) & 1);                       // logical chunk of the half tile
+        w_vo[i] = (uint32_t)(t128 * nkt32 * X3_TILE_BYTES + plane * (X3_TILE_BYTES / 2) + r128 * 64 + ((c ^ ((r128 >> 2) & 3)) << 4));
+    }
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt32 * X3_TILE_BYTES, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    auto dma = [&](int kt, int st) {
+        const int tap = CONV ? kt / nkt_tap : 0;
+        const int kh = CONV ? kt - tap * nkt_tap : kt;                   // half tile within the tap
+        if (CONV && kh == 0) {                         // first k tile of a tap: row shift + zero padding at the chain ends
+            const int shift = (tap - half) * p.dil;
+#pragma unroll
+            for (int i = 0; i < A_PIECES; ++i) {
+                const int sp = a_pos[i] + shift;
+                const bool v = a_ok[i] && sp >= 0 && sp < Lc;
+                a_vo[i] = v ? (uint32_t)((a_row[i] + shift) * p.lda * 4) + a_in[i] : BUF_OOB;
+            }
+        }
+        char* dst = St + st * STAGE_BYTES;
+        const int a_so = (kh >> 1) * 128 + (kh & 1) * 32;
+        const uint32_t flip = (uint32_t)(kt & 1) << 5;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], a_so, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(dst + A_BYTES + (NW * i + wave) * 1024), 16, (int)(w_vo[i] ^ flip),
+                                                     (kt >> 1) * X3_TILE_BYTES, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragments of row r = (wave part) + 32 t + (lane & 31), k octet g = lane >> 5: A high parts = chunk g, low parts = chunk 2 + g
+    // at position chunk ^ ((r >> 2) & 3) of the 64-byte row; W chunk g at position g ^ ((r >> 3) & 1) of the plane's 32-byte row
+    const int fg = lane >> 5;
+    const int aoff = (lane & 31) * 64 + ((fg ^ ((lane >> 2) & 3)) << 4);
+    const int woff = (lane & 31) * 32 + ((fg ^ ((lane >> 3) & 1)) << 4);
+    auto mma = [&](int st) {
+        const char* At = St + st * STAGE_BYTES + wm * WTM * 64;
+        const char* Wt = St + st * STAGE_BYTES + A_BYTES + wn * WTN * 32;
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(At + aoff + 32 * 64 * i);
+            al[i] = *reinterpret_cast<const f16x8*>(At + (aoff ^ 32) + 32 * 64 * i);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(Wt + woff + 32 * 32 * j);
+            bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_PLANE + woff + 32 * 32 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int PER_TILE = A_PIECES + W_PIECES, KEEP = (NS - 2) * PER_TILE;
+    static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
+    constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nkt) dma(t, t);
+    if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
+    lds_barrier();
+    int st = 0, st_in = NS - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + NS - 1 < nkt;
+        if (more && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
+        if (abl_mode != 1 && abl_mode != 3) mma(st);
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        lds_barrier();
+        st_in = st;
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+    if (p.x3_abl & 8) {                                // probe: no epilogue (the accumulators stay live through a never-true store)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1.2345678f) p.C[tid] = s;
+        return;
+    }
+    const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
+    const int need = epi_needs(p);
+#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
+    if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
+    else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
+    else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
+    else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
+    else HD_EPI(EPI_ALL);
+#undef HD_EPI
+}
+
+}  // namespace hd
+
+template <int BM, int BN, int WM, int WN, int NS>
+static float runh(GemmP q, int abl, double seconds, const char* tag) {
+    q.x3_abl = abl;
+    const int rows = q.sg.B * q.sg.len[0];
+    q.tiles0 = (rows + BM - 1) / BM; q.tiles_m = q.tiles0; q.tiles_n = q.N / BN;
+    dim3 grid(((q.tiles_m + 7) / 8) * 8 * q.tiles_n), blk(64 * WM * WN);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_x3h_k<BM, BN, WM, WN, false, NS>), grid, blk, 0, 0, q);
+    hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    int iters = 0; float ms_total = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((gemm_x3h_k<BM, BN, WM, WN, false, NS>), grid, blk, 0, 0, q);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms_total += ms; iters += 50;
+    }
+    printf("END   %s abl=0x%x  %.1f us per launch\n", tag, abl, 1e3 * ms_total / iters); fflush(stdout);
+    return ms_total / iters;
+}
+
+// results of two kernels on the same operands must be bit-identical in their K-sequential fp32 accumulation?  No: the k grouping
+// differs (16 vs 32 per MFMA pass order), so compare within a tolerance against each other
+static void compare(const float* dC, size_t n, std::vector<float>& ref, const char* tag) {
+    std::vector<float> got(n);
+    hipMemcpy(got.data(), dC, n * 4, hipMemcpyDeviceToHost);
+    if (ref.empty()) { ref = got; printf("CMP   %s reference taken (C[0] = %g, C[last] = %g)\n", tag, got[0], got[n - 1]); return; }
+    double mx = 0, mxr = 0;
+    for (size_t i = 0; i < n; ++i) { const double d = fabs((double)got[i] - ref[i]); if (d > mx) mx = d; if (fabs(ref[i]) > mxr) mxr = fabs(ref[i]); }
+    printf("CMP   %s max |diff| = %g of max |value| %g\n", tag, mx, mxr);
+}
+
 int main(int argc, char** argv) {
     const int M = 74496, K = 768, N = 1536;
     float *A, *C; uint16_t* Wx;
@@ -124,6 +359,35 @@ int main(int argc, char** argv) {
         g = q; g.bias = bias; g.c_split = 1; g.epi_act = ACT_RELU; go("7 bias + ReLU + split output (FF1)", g);
         g = q; g.bias = bias; g.c_split = 1; g.ln_fold = 1; g.stats = stats; go("8 folded LayerNorm + bias + split output (Q|K|V)", g);
         g = q; g.bias = bias; g.part = part; g.part_rows = M; go("9 bias + partials (PFF1 / tap GEMM)", g);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "half") {
+        // gemm_x3h_k (16-deep k tiles, two blocks per CU) against the shipping kernels on the Q|K|V shape
+        const double secs = 0.4;
+        p.st_nt = 1;
+        std::vector<float> ref;
+        const size_t ncmp = (size_t)4096 * N;
+        hipMemset(C, 0, (size_t)M * N * 4);
+        run<256, 256, 2, 4, 2>(p, 0, 0.05, "256x256x32 (shipping)"); compare(C, ncmp, ref, "256x256x32");
+        hipMemset(C, 0, (size_t)M * N * 4);
+        runh<256, 128, 2, 2, 2>(p, 0, 0.05, "256x128x16 NS=2"); compare(C, ncmp, ref, "256x128x16 NS=2");
+        hipMemset(C, 0, (size_t)M * N * 4);
+        runh<256, 128, 2, 2, 3>(p, 0, 0.05, "256x128x16 NS=3"); compare(C, ncmp, ref, "256x128x16 NS=3");
+        for (int abl : {0, 8, 9, 10, 3}) run<256, 256, 2, 4, 2>(p, abl, secs, "256x256x32 waves 2x4 (shipping)");
+        for (int abl : {0, 8, 9, 10, 3}) runh<256, 128, 2, 2, 2>(p, abl, secs, "256x128x16 NS=2 4 waves");
+        for (int abl : {0, 8, 9, 10, 3}) runh<256, 128, 2, 2, 3>(p, abl, secs, "256x128x16 NS=3 4 waves");
+        for (int abl : {0, 8}) runh<128, 128, 2, 2, 3>(p, abl, secs, "128x128x16 NS=3 4 waves");
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "tiles") {
+        // tile / wave-shape sweep on the Q|K|V shape: everything, no epilogue, epilogue only (round 4: where does the epilogue's time go)
+        const double secs = 0.4;
+        p.st_nt = 1;
+        for (int abl : {0, 8, 3, 32 + 3}) run<256, 256, 2, 4, 2>(p, abl, secs, "256x256 waves 2x4 (shipping)");
+        for (int abl : {0, 8, 3, 32 + 3}) run<256, 256, 4, 2, 2>(p, abl, secs, "256x256 waves 4x2 (wave tile 64 x 128)");
+        for (int abl : {0, 8, 3, 32 + 3}) run<128, 128, 2, 2, 2>(p, abl, secs, "128x128 waves 2x2");
+        for (int abl : {0, 8, 3, 32 + 3}) run<128, 128, 4, 1, 2>(p, abl, secs, "128x128 waves 4x1 (wave tile 32 x 128)");
+        fill_test(C, (size_t)M * N * 4);
         return 0;
     }
     const double secs = 0.6;
