@@ -264,15 +264,14 @@ def timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, precision, steps,
 
 
 DTYPE_OF_ROUTE = {
-    "split": "f32-equivalent: fp16 hi+lo split, 3 MFMA / product, f32 accumulate; launches < 1024 rows f32",
+    "split": "f32-equivalent: fp16 hi+lo split, 3 MFMA / product, f32 accumulate; pruned tail + static branch f32",
     "f32_gemm": "f32 MFMA GEMMs; attention core f32-equivalent (fp16 hi+lo split, 3 MFMA / product, f32 accumulate)",
     "f32_all": "f32 (every product on the fp32 MFMA pipe)",
 }
 DTYPE_DETAIL = {
     "split": "every large GEMM (Q|K|V, out-projection, FF, ByteNet projections and taps) and the attention core (QK^T, PV): each fp32 operand "
              "as fp16 hi + fp16 lo (22 significand bits), a w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi as three v_mfma_f32_32x32x16_f16 / "
-             "16x16x32_f16 with fp32 accumulation; softmax, LayerNorm, residuals, dropout, decoder in fp32; launches of fewer than 1024 "
-             "activation rows, the pruned tail's compact GEMMs and the static branch on fp32 MFMA; range guard (|x| >= 65504) and ln_sync "
+             "16x16x32_f16 with fp32 accumulation; softmax, LayerNorm, residuals, dropout, decoder in fp32; the pruned tail's compact GEMMs and the static branch on fp32 MFMA; range guard (|x| >= 65504) and ln_sync "
              "guard repeat the call on fp32 / ln_apply_k kernels (precision_info)",
     "f32_gemm": "GEMMs (90.5 % of the FLOPs): fp32 MFMA v_mfma_f32_32x32x2_f32; attention core (9.5 %): three fp16 MFMAs per product on "
                 "fp16 (hi, lo) splits of the fp32 Q / K / V / P, fp32 accumulation and softmax",

@@ -100,11 +100,12 @@ static long big_rows() {
     static long n = [] { const char* e = getenv("HUDIFF_BIG_ROWS"); long v = e ? atol(e) : 8192; return v < 1 ? 1 : v; }();
     return n;
 }
-// Split-precision launches need fewer rows to pay: the 128 x 128 split kernels beat the generic fp32 ones from ~1 000 activation rows on
-// (round 4 sweep, profiles/r04/small_batch_sweep.txt: B = 16 antibodies 25.2 -> 35.6 sequences/s, B = 24 29.6 -> 47.2, B = 8 17.6 ->
-// 20.0; the fp32 big-launch kernels gain nothing below 8192 rows).  HUDIFF_X3_ROWS: tuning aid (default 1024).
+// Split-precision launches pay from a single sequence on: with tiles sized to the grid (launch_gemm: 64 x 128 / 32 x 128 tiles for
+// under-filled grids) the split kernels beat the generic fp32 ones at every batch size (round 4 sweeps, profiles/r04/small_batch_*.txt:
+// B = 1 antibody 2.65 -> 3.45 sequences/s, B = 8 17.6 -> 26.2, B = 16 25.2 -> 41.2, B = 24 29.6 -> 48; the fp32 big-launch kernels gain
+// nothing below 8192 rows).  HUDIFF_X3_ROWS: tuning aid (default 128).
 static long x3_rows() {
-    static long n = [] { const char* e = getenv("HUDIFF_X3_ROWS"); long v = e ? atol(e) : 1024; return v < 1 ? 1 : v; }();
+    static long n = [] { const char* e = getenv("HUDIFF_X3_ROWS"); long v = e ? atol(e) : 128; return v < 1 ? 1 : v; }();
     return n;
 }
 static int lanes_default() {
@@ -894,7 +895,7 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     hipStream_t st = cur(m).stream;
     const long rows = (long)p.sg.B * p.sg.L;
     const bool big = rows >= big_rows() || p.Wx != nullptr;      // (split-precision launches: x3_use() decided)
-    const int pw = big ? 64 : 32;
+    int pw = big ? 64 : 32;                              // column-slice width of the LayerNorm partials this launch leaves (its waves' WTN)
     p.part_rows = rows;
     // non-temporal epilogue stores: +0.9 % on the split-precision sample (3 x 3 interleaved runs; gemm_x3_k always uses them),
     // nothing on the fp32 one (HUDIFF_ST_NT=1 turns them on there)
@@ -935,7 +936,15 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         int shape = (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) ? 512 : 128;
         if (force == 128 || force == 256 || (force == 512 && q.N % 256 == 0)) shape = force;
         if (q.ln_sync) shape = 128;                     // the meeting epilogue exists in the 4-wave 128 x 128 instantiation only
-        const int bm = shape == 128 ? 128 : 256, bn = shape == 512 ? 256 : 128;
+        // under-filled grids (mid-size batches): 64 x 128 tiles double the blocks of a launch whose 128 x 128 grid leaves CUs idle or
+        // with one latency-bound block each.  HUDIFF_X3_SMALL_GRID = largest 128 x 128 grid that takes them (300: B = 8 antibodies
+        // 20.0 -> 25.1 sequences/s, B = 16 36.5 -> 42.4, B = 48 73.3 -> 78.4; larger limits lose again).
+        static const long small_grid = [] { const char* e = getenv("HUDIFF_X3_SMALL_GRID"); return e ? atol(e) : 300L; }();
+        if (shape == 128 && ((rows0 + 127) / 128 + (rows1 + 127) / 128) * (long)(q.N / 128) <= small_grid) shape = 64;
+        // ... and 32 x 128 tiles (four waves side by side, 32 x 32 each) when even those leave most CUs empty (a handful of sequences)
+        static const long tiny_grid = [] { const char* e = getenv("HUDIFF_X3_TINY_GRID"); return e ? atol(e) : 150L; }();
+        if (shape == 64 && ((rows0 + 63) / 64 + (rows1 + 63) / 64) * (long)(q.N / 128) <= tiny_grid) { shape = 32; pw = 32; }
+        const int bm = shape <= 64 ? shape : (shape == 128 ? 128 : 256), bn = shape == 512 ? 256 : 128;
         q.tiles0 = (rows0 + bm - 1) / bm;
         q.tiles_m = q.tiles0 + (rows1 + bm - 1) / bm;
         q.tiles_n = q.N / bn;
@@ -946,6 +955,12 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         } else if (shape == 256) {
             if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, true, 3>), grid, dim3(512), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, false, 3>), grid, dim3(512), 0, st, q);
+        } else if (shape == 32) {
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 2>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 2>), grid, dim3(256), 0, st, q);
+        } else if (shape == 64) {
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);
         } else {
             if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);

@@ -552,7 +552,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             __syncthreads();
             // ---- (mean, rstd) of this wave's WTM rows from ALL slices of the row: lane r merges row r (Chan et al.) -----
             const int P = p.tiles_n * WN;
-            constexpr int PMAX = 16;                                     // N <= 1024 with 64-wide slices
+            constexpr int PMAX = WTN >= 64 ? 16 : 32;                    // N <= 1024 with 64-wide (32-wide: 32 x 128 tiles) slices
             for (int r = lane; r < WTM; r += 64) {
                 const int lrow = m0 + wm * WTM + r;
                 float2 st = make_float2(0.f, 0.f);

@@ -176,7 +176,7 @@ double hd_flops_per_row_sample_step(const HdConfig* cfg);
  *   HD_PRECISION_SPLIT     every large GEMM and the attention core as THREE fp16 MFMAs per fp32 product: each operand is hi + lo with
  *                          hi = fp16(x), lo = fp16(x - hi) (22 significand bits; x - hi is exact), a w ~= a_hi w_hi + a_hi w_lo +
  *                          a_lo w_hi with fp32 accumulation -- as close to the exact dot product as the fp32 kernels.  Launches of
- *                          fewer than 1024 activation rows (4 antibodies / 7 nanobodies), the pruned tail's compact GEMMs and the
+ *                          fewer than 128 activation rows (none of the two models' single sequences), the pruned tail's compact GEMMs and the
  *                          static branch run the fp32 kernels.
  *   HD_PRECISION_F32_GEMM  GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32); only the attention core (QK^T, PV) of launches
  *                          >= 8192 rows as three fp16 MFMAs per product (the round-3 default)

@@ -129,7 +129,7 @@ def test_default_bench_line_carries_the_measurement_contract(tmp_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["unit"] == "sequences/s" and d["vs_baseline"] is None and d["higher_is_better"] is True
-    assert d["precision_route"] == "split" and "fp16 hi+lo split, 3 MFMA / product" in d["dtype"] and "< 1024 rows f32" in d["dtype"]
+    assert d["precision_route"] == "split" and "fp16 hi+lo split, 3 MFMA / product" in d["dtype"] and "pruned tail + static branch f32" in d["dtype"]
     assert "HuAb348" in d["metric"] and "workload" in d["config"] and d["config"]["rows_per_gpu"] == 64
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"].startswith("TFLOP/s") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
