@@ -40,7 +40,7 @@ class HdConfig(C.Structure):
 
 class HdPrecisionInfo(C.Structure):
     _fields_ = [("precision", C.c_int32), ("split_built", C.c_int32), ("split_in_use", C.c_int32), ("lnsync_in_use", C.c_int32),
-                ("range_fallbacks", C.c_int64), ("lnsync_fallbacks", C.c_int64), ("last_call_repeated", C.c_int32), ("reserved", C.c_int32)]
+                ("range_fallbacks", C.c_int64), ("lnsync_fallbacks", C.c_int64), ("last_call_repeated", C.c_int32), ("lnsync_cross_xcd", C.c_int32)]
 
 
 class HudiffError(RuntimeError):

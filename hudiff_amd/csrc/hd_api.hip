@@ -140,6 +140,7 @@ struct HdModel {
     int lnsync_level_cfg = 2, lnsync_level = 2;      // 0 = ln_apply_k passes, 1 = the two inner GEMMs of a ByteNet block normalise their own output, 2 = the last GEMM as well
     int64_t lnsync_fallbacks = 0;
     bool last_call_repeated = false;                 // the last hd_forward / hd_sample_end repeated its call (either guard)
+    bool lnsync_cross_xcd = false;                   // some ln_sync meeting saw its blocks on two XCDs (the placement premise of its speed did not hold)
     const float* emb = nullptr;
     std::vector<ByteNetW> enc, conv;
     std::vector<AttBlockW> att;
@@ -1371,14 +1372,15 @@ static void suspend_lnsync(HdModel* m, uint32_t bits) {
 // begin / restart invalid (m->s_dirty): the caller repeats them.  One guard per round: a failed meeting leaves garbage that can trip
 // the range guard too, so the range flag of such a run is not believed -- the repeat raises it again if it is real.
 static HdStatus check_guards(HdModel* m, int nlanes, bool* numeric) {
-    uint32_t pad[3] = {0, 0, 0};
+    uint32_t pad[4] = {0, 0, 0, 0};
     for (int l = 0; l < nlanes; ++l) HIP_TRY(hipStreamSynchronize(m->lane[l].stream));
     for (int l = 0; l < nlanes; ++l) {
         RunState h{};
         HIP_TRY(hipMemcpy(&h, m->lane[l].rs, sizeof(h), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 3; ++i) pad[i] |= h.pad[i];
+        for (int i = 0; i < 4; ++i) pad[i] |= h.pad[i];
     }
     if (numeric) *numeric = pad[0] != 0;
+    if (pad[3]) m->lnsync_cross_xcd = true;         // an ln_sync meeting spanned two XCDs: correct (write-through hand-over), slower
     if (m->s_dirty) return HD_OK;                   // already known; nothing more is read out of an invalid run
     if (pad[2] && m->x3 && !m->x3_suspended && m->lnsync_level > 0) { suspend_lnsync(m, pad[2]); m->s_dirty = true; }
     else if (pad[1] && split_active(m)) { suspend_split(m); m->s_dirty = true; }
@@ -1731,6 +1733,7 @@ extern "C" HdStatus hd_precision_report(HdModel* m, HdPrecisionInfo* out, size_t
     r.range_fallbacks = m->range_fallbacks;
     r.lnsync_fallbacks = m->lnsync_fallbacks;
     r.last_call_repeated = m->last_call_repeated ? 1 : 0;
+    r.lnsync_cross_xcd = m->lnsync_cross_xcd ? 1 : 0;
     memcpy(out, &r, size < sizeof(r) ? size : sizeof(r));
     return HD_OK;
 }

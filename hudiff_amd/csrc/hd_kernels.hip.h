@@ -497,8 +497,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         __builtin_amdgcn_wave_barrier();
         for (int r = lane; r < WTM; r += 64) {
             const int lrow = m0 + wm * WTM + r;
-            if (lrow < seg_rows && nv > 0)
-                p.part[(long)(by * WN + wn) * p.part_rows + rbase + lrow] = wpart[r];
+            if (lrow < seg_rows && nv > 0) {
+                float2* dst = p.part + (long)(by * WN + wn) * p.part_rows + rbase + lrow;
+                if ((F & EPI_LNSYNC) && ln_sync) {
+                    // read by OTHER workgroups of this launch (the meeting below): an agent-scope relaxed atomic store = a write-through
+                    // (sc1) store, visible to agent-scope (sc1) loads once this wave's vmcnt has drained -- whatever XCD the reader is on
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), __builtin_bit_cast(unsigned long long, wpart[r]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *dst = wpart[r];
+                }
+            }
         }
     }
     if constexpr ((F & EPI_LNSYNC) != 0) {
@@ -524,13 +533,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 __syncthreads();
             } else {
             // ---- meet the other N tiles of this M tile ------------------------------------------------------------------
-            // All tiles_n blocks of an M tile sit on ONE XCD (XCD-aware tile order) and therefore behind one L2: a store that has
-            // left the CU (vmcnt(0): the vector L1 is write-through) is visible to any load that bypasses the reader's L1.  So the
-            // hand-over needs no device-scope fence -- on gfx950 that is a write-back + invalidate of the XCD's whole L2, measured at
-            // 2x the time of the entire step when every block did it -- only this wave's stores drained before the arrival is
-            // counted, and L1-bypassing (agent-scope, relaxed) loads of the partials afterwards.  The one-XCD premise is an
-            // observed property of the dispatcher, so it is CHECKED: every block ORs its XCC id into the tile's third counter and
-            // a tile whose blocks saw more than one id raises RunState::pad[2] (the host then refuses the result).
+            // Hand-over of the slice partials between the tiles_n workgroups of an M tile, without a device-scope fence (on gfx950 a
+            // release at agent scope is a write-back of the XCD's whole L2: measured at 2x the time of the entire step when every block
+            // did it).  The recipe of the programming guide's Guideline 16 in its write-through form: the partials are stored with
+            // agent-scope relaxed atomic stores (sc1: written through), every wave drains its vmcnt, the block's arrival is counted
+            // with a relaxed agent-scope atomic, and the readers poll relaxed and load the partials with agent-scope relaxed atomic
+            // loads (sc1: past the L1).  Correct wherever the workgroups run; FAST because the XCD-aware tile order puts all N tiles of
+            // an M tile on one XCD's L2 at the same time (round 3 relied on that placement for correctness too and checked it; the
+            // check stays as a counter of the premise, a mixed placement is no longer an error).  Progress needs the tiles_n blocks
+            // co-resident: dispatch is in order per XCD and a group's missing members are the next to be dispatched; a meeting that
+            // exceeds its polling budget raises RunState::pad[2] and the host repeats the call with ln_apply_k passes -- never a hang.
             // Nothing but the partials has been stored so far (loads and stores share one in-order counter on this ISA: bulk
             // stores ahead of the polls and of the partial loads would put their whole drain time into the meeting).
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -547,7 +559,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.tiles_n && --budget > 0)
                     __builtin_amdgcn_s_sleep(1);
                 const int seen = __hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (budget <= 0 || (seen & (seen - 1))) atomicOr(const_cast<uint32_t*>(&p.rs->pad[2]), budget <= 0 ? 1u : 2u);
+                if (budget <= 0) atomicOr(const_cast<uint32_t*>(&p.rs->pad[2]), 1u);
+                else if (seen & (seen - 1)) atomicOr(const_cast<uint32_t*>(&p.rs->pad[3]), 1u);      // placed on two XCDs: slower, not wrong (counted)
             }
             __syncthreads();
             // ---- (mean, rstd) of this wave's WTM rows from ALL slices of the row: lane r merges row r (Chan et al.) -----

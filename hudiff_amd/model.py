@@ -268,7 +268,8 @@ class _Denoiser:
         L.check(self._lib.hd_precision_report(self._h, C.byref(r), C.sizeof(r)))
         return {"precision": L.PRECISION_NAMES[int(r.precision)], "split_built": int(r.split_built), "split_in_use": bool(r.split_in_use),
                 "lnsync_in_use": bool(r.lnsync_in_use), "range_fallbacks": int(r.range_fallbacks),
-                "lnsync_fallbacks": int(r.lnsync_fallbacks), "last_call_repeated": bool(r.last_call_repeated)}
+                "lnsync_fallbacks": int(r.lnsync_fallbacks), "last_call_repeated": bool(r.last_call_repeated),
+                "lnsync_cross_xcd": bool(r.lnsync_cross_xcd)}
 
     def precision_reset(self):
         """hd_precision_reset: back on the configured route after a guard switched kernels off."""

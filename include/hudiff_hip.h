@@ -193,9 +193,10 @@ double hd_flops_per_row_sample_step(const HdConfig* cfg);
  *                 its values; when one is out of range, hd_forward / hd_sample[_end] repeats the whole call on the fp32 kernels (same
  *                 resident inputs, same noise key, same steps) and the handle stays on them (weights whose stream leaves the
  *                 range do so at every step) until hd_precision_reset.  hd_sample_restart and hd_sync notice the flag as well.
- *   ln_sync guard the ByteNet GEMMs of the split route normalise their own output rows: the N tiles of an M tile meet at an L2-level
- *                 counter, which presumes they run together on one XCD.  A meeting that times out or sees two XCDs raises a flag;
- *                 the call is repeated with separate LayerNorm passes (ln_apply_k) and the handle keeps those.                    */
+ *   ln_sync guard the ByteNet GEMMs of the split route normalise their own output rows: the N tiles of an M tile exchange LayerNorm
+ *                 partials at a counter (write-through stores, agent-scope loads: correct wherever the blocks run), which presumes
+ *                 they are co-resident.  A meeting that times out raises a flag; the call is repeated with separate LayerNorm passes
+ *                 (ln_apply_k) and the handle keeps those.                                                                          */
 enum { HD_PRECISION_DEFAULT = 0, HD_PRECISION_F32_GEMM = 1, HD_PRECISION_F32_ALL = 2, HD_PRECISION_SPLIT = 3 };
 HdStatus hd_set_precision(HdModel* m, int32_t precision);
 typedef struct HdPrecisionInfo {
@@ -206,7 +207,7 @@ typedef struct HdPrecisionInfo {
     int64_t range_fallbacks;    /* calls repeated on the fp32 kernels by the range guard                                          */
     int64_t lnsync_fallbacks;   /* calls repeated with ln_apply_k passes because an ln_sync meeting failed                        */
     int32_t last_call_repeated; /* 1 if the last hd_forward / hd_sample_end repeated its call (hd_last_run_ms then times the repeat) */
-    int32_t reserved;
+    int32_t lnsync_cross_xcd;   /* 1 once an ln_sync meeting saw its blocks on two XCDs: still correct (write-through hand-over), slower */
 } HdPrecisionInfo;
 /* size = sizeof(HdPrecisionInfo) of the caller (fields beyond it are not written) */
 HdStatus hd_precision_report(HdModel* m, HdPrecisionInfo* out, size_t size);
