@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhudiff_hip.so")
 SOURCES = [os.path.join(CSRC, "hd_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"), os.path.join(CSRC, "hd_enc_fused.hip.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hudiff_hip.h")]
 
 
@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", "-Wno-unused-value", *SOURCES, "-o", LIB]
+           "-Wno-unused-result", "-Wno-unused-value", *os.environ.get("HUDIFF_CXXFLAGS", "").split(), *SOURCES, "-o", LIB]
     if verbose:
         print("[hudiff_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

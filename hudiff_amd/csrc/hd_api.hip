@@ -7,6 +7,7 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails with HD_ERR_NO_DEVICE.
 #include "../../include/hudiff_hip.h"
 #include "hd_kernels.hip.h"
+#include "hd_enc_fused.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -1250,9 +1251,43 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     Workspace& ws = cur(m).ws;
     const HdConfig& c = m->cfg;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
-    hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
     const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
-    for (int n = 0; n < c.n_encoder_layers; ++n) {
+    // The token-encoder stack as ONE kernel (hd_enc_fused.hip.h): split route, the shipped widths (256 / 128, kernel 7), chains of at
+    // most 160 slots.  OFF by default (HUDIFF_ENC_FUSED=1 turns it on): correct to 1e-6 of the per-GEMM launches, but measured slower --
+    // 597 us per (sequence, chain) workgroup against 290 us for the 36 launches at B = 1, 731 against ~735 us per 128-sequence lane:
+    // with one wave per SIMD (x register-resident) the LayerNorm / GELU / split passes cannot overlap the MFMAs.
+    static const bool enc_fused_on = [] { const char* e = getenv("HUDIFF_ENC_FUSED"); return e && atoi(e) == 1; }();
+    bool enc_fused = enc_fused_on && m->x3 && !m->x3_suspended && d == 256 && dh == 128 && c.kernel_size == 7 &&
+                     c.n_encoder_layers >= 1 && c.n_encoder_layers <= ENC_MAX_LAYERS && sg.len[0] <= ENC_ROWS && (sg.nseg == 1 || sg.len[1] <= ENC_ROWS);
+    for (int n = 0; enc_fused && n < c.n_encoder_layers; ++n) enc_fused = m->enc[n].w1x.w && m->enc[n].wcx.w && m->enc[n].w3x.w;
+    if (enc_fused) {
+        EncStackP ep{};
+        for (int sgi = 0; sgi < sg.nseg; ++sgi)
+            for (int n = 0; n < c.n_encoder_layers; ++n) {
+                const ByteNetW& w = m->enc[n];
+                EncLayerW& l = ep.lw[sgi][n];
+                l.w1 = w.w1x.w + (long)sgi * w.w1x.seg_stride; l.wc = w.wcx.w + (long)sgi * w.wcx.seg_stride; l.w3 = w.w3x.w + (long)sgi * w.w3x.seg_stride;
+                l.s1 = w.w1x.acc_scale; l.sc = w.wcx.acc_scale; l.s3 = w.w3x.acc_scale; l.dil = w.dil;
+                l.b1 = w.b1 + sgi * dh; l.bc = w.bc + sgi * dh; l.b3 = w.b3 + sgi * d;
+                l.g1 = w.ln1_g + sgi * d; l.e1 = w.ln1_b + sgi * d; l.g2 = w.ln2_g + sgi * dh; l.e2 = w.ln2_b + sgi * dh;
+                l.g3 = w.ln3_g + sgi * dh; l.e3 = w.ln3_b + sgi * dh;
+            }
+        ep.nlayers = c.n_encoder_layers; ep.act = c.enc_act;
+        ep.tokens = ws.tokens; ep.emb = m->emb; ep.extra = ws.EXTRA; ep.lde = d; ep.out = ws.FEAT; ep.ldo = D; ep.sg = sg; ep.rs = cur(m).rs;
+        static const int enc_abl = [] { const char* e = getenv("HUDIFF_ENC_ABL"); return e ? atoi(e) : 0; }();
+        ep.abl = enc_abl;
+        ep.drop_mode = (drop_mode != DROP_NONE && m->p_enc > 0.f) ? drop_mode : DROP_NONE;
+        if (ep.drop_mode != DROP_NONE) {
+            GemmP tmp{}; Drop dr; dr.mode = drop_mode; dr.p = m->p_enc;
+            set_drop(tmp, dr);
+            ep.drop_thresh = tmp.drop_thresh; ep.drop_scale = tmp.drop_scale;
+            ep.drop_mask = enc_masks; ep.mask_layer_stride = (long)enc_stride;
+        }
+        if (c.enc_act == HD_ACT_GELU) hipLaunchKernelGGL(enc_stack_x3_k<ACT_GELU>, dim3(sg.B, sg.nseg), dim3(256), 0, st, ep);
+        else hipLaunchKernelGGL(enc_stack_x3_k<ACT_RELU>, dim3(sg.B, sg.nseg), dim3(256), 0, st, ep);
+    } else
+    hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
+    for (int n = 0; !enc_fused && n < c.n_encoder_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
