@@ -1704,8 +1704,11 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                     split4(o, hh, ll);
                     if (HD_GUARD_MASK & 4) vmax = absmax4(vmax, o);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
-                    *reinterpret_cast<f16x4*>(orow + x16_hi(col)) = hh;
-                    *reinterpret_cast<f16x4*>(orow + x16_hi(col) + X16_LO) = ll;
+                    // x16_hi(64 h + 16 dt + 4 g) with dt a compile-time constant: lane part 128 h + 4 g, the rest an immediate (the
+                    // generic shift-and-mask form cost the 128-VGPR kernels six to eight spilled registers)
+                    const int oc = 128 * h + 4 * g + 64 * (dt >> 1) + 16 * (dt & 1);
+                    *reinterpret_cast<f16x4*>(orow + oc) = hh;
+                    *reinterpret_cast<f16x4*>(orow + oc + X16_LO) = ll;
                 } else {
                     *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
                 }
@@ -1990,8 +1993,11 @@ __global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_
                     f16x4 hh, ll;
                     split4(o, hh, ll);
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
-                    *reinterpret_cast<f16x4*>(orow + x16_hi(col)) = hh;
-                    *reinterpret_cast<f16x4*>(orow + x16_hi(col) + X16_LO) = ll;
+                    // x16_hi(64 h + 16 dt + 4 g) with dt a compile-time constant: lane part 128 h + 4 g, the rest an immediate (the
+                    // generic shift-and-mask form cost the 128-VGPR kernels six to eight spilled registers)
+                    const int oc = 128 * h + 4 * g + 64 * (dt >> 1) + 16 * (dt & 1);
+                    *reinterpret_cast<f16x4*>(orow + oc) = hh;
+                    *reinterpret_cast<f16x4*>(orow + oc + X16_LO) = ll;
                 } else {
                     *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
                 }
