@@ -314,6 +314,41 @@ def test_lnsync_guard_repeats_the_call_with_layernorm_passes(hip, kind):
         m32.close(); mx3.close()
 
 
+@pytest.mark.parametrize("kind", ["ab", "nb"])
+def test_small_batches_take_the_split_tiles_and_hold_the_bound(hip, kind):
+    """Round 4: split launches start at one sequence, on tiles sized to the grid (32 x 128, 64 x 128, 128 x 128; hd_api.hip launch_gemm).
+    Batches that land on each shape: logits within 1e-4 of a float64 evaluation of the oracle (as close as the all-fp32 route), within 1e-4
+    of the all-fp32 route on every row, repeatable bit for bit, and short samples give the all-fp32 route's tokens."""
+    from conftest import prec
+    from hudiff_amd import evalsets as E
+    cfg, sd, m32, mx3 = _pair(hip, kind, seed=0)
+    try:
+        net64 = ho.OracleNet(kind, dict(cfg, dropout=0.0), sd, dtype=np.float64)
+        for B in (1, 3, 9, 20):                      # 291 ... 5 820 antibody rows / 152 ... 3 040 nanobody rows
+            batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=17)
+            tokens = batch["tokens"].copy()
+            for b in range(B):
+                loc = batch["order"][b, :batch["T"][b] // 2]
+                tokens[b, loc] = batch["truth"][b, loc]
+            a = m32(tokens, batch["region"], batch["chain"], dropout="off")
+            x = mx3(tokens, batch["region"], batch["chain"], dropout="off")
+            assert np.array_equal(x, mx3(tokens, batch["region"], batch["chain"], dropout="off"))
+            n64 = min(B, 2)
+            ch64 = None if batch["chain"] is None else np.concatenate([batch["chain"][:n64], batch["chain"][B:B + n64]])
+            o64 = net64(tokens[:n64], batch["region"][:n64], ch64)
+            e32, ex3 = np.abs(a[:n64] - o64).max(), np.abs(x[:n64] - o64).max()
+            assert ex3 < LOGIT_TOL and ex3 < 3 * max(e32, 2e-6), (B, ex3, e32)
+            assert 0.0 < np.abs(a - x).max() < LOGIT_TOL, B                  # the split kernels really ran, and agree
+            kw = dict(dropout="faithful", seed=4, row0=2, step=9)
+            assert np.abs(m32(tokens, batch["region"], batch["chain"], **kw) - mx3(tokens, batch["region"], batch["chain"], **kw)).max() < LOGIT_TOL
+            T5 = np.minimum(batch["T"], 5)
+            args = (batch["tokens"], batch["region"], batch["chain"], batch["order"], T5)
+            assert np.array_equal(mx3.sample(*args, seed=6, row0=0), m32.sample(*args, seed=6, row0=0)), B
+        prec(mx3, precision="split", split_in_use=True, range_fallbacks=0, lnsync_fallbacks=0)
+    finally:
+        m32.close(); mx3.close()
+
+
 def test_fused_token_encoder_kernel_matches_the_per_gemm_launches():
     """hd_enc_fused.hip.h (HUDIFF_ENC_FUSED=1; off by default, measured slower): the whole token-encoder stack as one kernel per
     (sequence, chain) must reproduce the 36 per-GEMM launches -- stack output and logits to ~1e-5 with dropout on and off, the same
