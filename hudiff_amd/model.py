@@ -103,6 +103,7 @@ class _Denoiser:
                 raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}, got {precision!r}")
             L.check(self._lib.hd_set_precision(self._h, L.PRECISIONS[precision]))
         self._loaded = False
+        self._seen_fallbacks = (0, 0)
         self.device_index = int(device)
 
     # -- nn.Module-shaped surface ---------------------------------------------------------------
@@ -151,6 +152,23 @@ class _Denoiser:
         except Exception:
             pass
 
+    def _warn_on_guard(self):
+        """A guard of the split-precision kernels repeated the last call on safer kernels (results are correct; the handle is slower
+        from here on until precision_reset()): say so once per event -- the C library only counts it (hd_precision_report)."""
+        r = L.HdPrecisionInfo()
+        if self._lib.hd_precision_report(self._h, C.byref(r), C.sizeof(r)) != L.HD_OK:
+            return
+        now = (int(r.range_fallbacks), int(r.lnsync_fallbacks))
+        if now != self._seen_fallbacks:
+            import warnings
+            what = []
+            if now[0] > self._seen_fallbacks[0]:
+                what.append("an activation left the fp16 range (|x| >= 65504): the call was repeated on the all-fp32 kernels and the handle stays on them")
+            if now[1] > self._seen_fallbacks[1]:
+                what.append("an ln_sync meeting failed: the call was repeated with separate LayerNorm passes and the handle keeps them")
+            self._seen_fallbacks = now
+            warnings.warn("hudiff_amd: " + "; ".join(what) + " (precision_info(); precision_reset() re-arms the split kernels)", RuntimeWarning, stacklevel=3)
+
     # -- forward ---------------------------------------------------------------------------------
     def _prep(self, tokens, region, chain):
         tok, was_torch = _to_numpy(tokens)
@@ -188,6 +206,7 @@ class _Denoiser:
         L.check(self._lib.hd_forward(self._h, L.ptr(tok, C.c_int32), L.ptr(reg, C.c_int32), L.ptr(chn, C.c_int32),
                                      B, self._flags(dropout), int(seed), int(row0), int(step),
                                      L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8), L.ptr(logits, C.c_float)))
+        self._warn_on_guard()
         if was_torch:
             import torch
             return torch.from_numpy(logits)
@@ -219,6 +238,7 @@ class _Denoiser:
                                     L.ptr(order, C.c_int32), L.ptr(T, C.c_int32), B, Tmax,
                                     self._flags(dropout, graph, prune, lanes), int(seed), int(row0), L.ptr(q, C.c_float),
                                     L.ptr(em, C.c_uint8), L.ptr(cm, C.c_uint8)))
+        self._warn_on_guard()
         if was_torch:
             import torch
             return torch.from_numpy(out.astype(np.int64))
@@ -246,6 +266,7 @@ class _Denoiser:
     def sample_end(self):
         out = np.empty((self._session_B, self.max_len), dtype=np.int32)
         L.check(self._lib.hd_sample_end(self._h, L.ptr(out, C.c_int32)))
+        self._warn_on_guard()
         return out
 
     def sample_tokens(self):
@@ -274,6 +295,9 @@ class _Denoiser:
     def precision_reset(self):
         """hd_precision_reset: back on the configured route after a guard switched kernels off."""
         L.check(self._lib.hd_precision_reset(self._h))
+        r = L.HdPrecisionInfo()
+        if self._lib.hd_precision_report(self._h, C.byref(r), C.sizeof(r)) == L.HD_OK:
+            self._seen_fallbacks = (int(r.range_fallbacks), int(r.lnsync_fallbacks))
 
     def debug_fail_next_lnsync(self):
         L.check(self._lib.hd_debug_fail_next_lnsync(self._h))

@@ -100,7 +100,8 @@ def test_range_guard_inside_a_sampling_session(hip, kind):
         fill, tokens, region, chain = _big_batch(kind, z, B)
         T = np.minimum(fill["T"], 5)
         args = (tokens, region, chain, fill["order"], T)
-        got = mx.sample(*args, seed=21, row0=7)
+        with pytest.warns(RuntimeWarning, match="left the fp16 range"):      # the Python mirror says so (the C library counts it)
+            got = mx.sample(*args, seed=21, row0=7)
         prec(mx, precision="split", split_built=3, split_in_use=False, range_fallbacks=1, lnsync_fallbacks=0, last_call_repeated=True)
         want = m32.sample(*args, seed=21, row0=7)
         assert np.array_equal(got, want)
