@@ -8,6 +8,7 @@
 #include "../../include/hudiff_hip.h"
 #include "hd_kernels.hip.h"
 #include "hd_enc_fused.hip.h"
+#include "hd_tail_fused.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -1155,6 +1156,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= big_rows())) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
+    // few sequences: two workgroups per (sequence, head), each with half of the query tiles (one round of the tile loop instead of two)
+    static const int ax_split_max = [] { const char* e = getenv("HUDIFF_ATTN_QSPLIT_MAX"); return e ? atoi(e) : 128; }();
+    if (ax_ok && (int)grid.x <= ax_split_max) grid.y = 2;
     static const bool ax_w8 = [] { const char* e = getenv("HUDIFF_ATTN_WAVES"); return e && atoi(e) == 8; }();
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19 && !ax_w8)
         hipLaunchKernelGGL((attn_x3_k<19, AX19_THREADS>), grid, dim3(AX19_THREADS), lds_request(AxGeom<19>::SMEM, AX19_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
@@ -1193,6 +1197,32 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
     return HD_OK;
 }
 
+// Forms of the pruned tail (hd_tail_fused.hip.h).  HUDIFF_TAIL: 0 = the separate launches below, 1 = one kernel per step (one workgroup
+// per sequence, the draw included), 2 = five sliced launches + sample_step_k: the default for lanes of at most HUDIFF_TAIL_MAX_B (64)
+// sequences, where the tail is a visible part of a step; above, the separate launches are as fast or faster (Nb, 512 sequences: 465
+// against 455 sequences/s).
+enum { TAIL_LAUNCHES = 0, TAIL_ONE = 1, TAIL_SLICED = 2 };
+static int tail_form(const HdModel* m, int B) {
+    static const int want = [] { const char* e = getenv("HUDIFF_TAIL"); return e ? atoi(e) : (int)TAIL_SLICED; }();
+    static const bool value_via_rows = [] { const char* e = getenv("HUDIFF_PRUNE_V"); return !(e && atoi(e) == 0); }();
+    const int D = m->D, A = m->A, Fd = m->Fd;
+    const bool one_ok = value_via_rows && m->cfg.nhead <= RV_MAX_HEADS && m->cfg.nhead * ATT_HD == A && m->L <= TAIL_MAXL && D <= TAIL_MAXD && D % 8 == 0 &&
+                        A <= TAIL_MAXA && A % 64 == 0 && Fd <= TAIL_MAXF && Fd % 2 == 0 && D / 4 <= TAIL_THREADS;
+    const bool sliced_ok = one_ok && (D == 768 || D == 512) && A == 512 && Fd == 256 && m->cfg.nhead == 8;      // the shipped widths
+    static const int max_b = [] { const char* e = getenv("HUDIFF_TAIL_MAX_B"); return e ? atoi(e) : 64; }();
+    if (want == TAIL_SLICED) return sliced_ok && B <= max_b ? TAIL_SLICED : TAIL_LAUNCHES;
+    if (want == TAIL_ONE) return one_ok ? TAIL_ONE : TAIL_LAUNCHES;
+    return TAIL_LAUNCHES;
+}
+template <int D>
+static void launch_tail_sliced(const TailP& t, int B, int nhead, int Fd, hipStream_t st) {
+    hipLaunchKernelGGL(tail_pw_k<D>, dim3(B, nhead), dim3(TC_THREADS), 0, st, t);
+    hipLaunchKernelGGL(tail_val_k<D>, dim3(B, D / TC_SLICE), dim3(TC_THREADS), 0, st, t);
+    hipLaunchKernelGGL(tail_out_k<D>, dim3(B, D / TC_SLICE), dim3(TC_THREADS), 0, st, t);
+    hipLaunchKernelGGL(tail_ff1_k<D>, dim3(B, Fd / 64), dim3(TC_THREADS), 0, st, t);
+    hipLaunchKernelGGL(tail_ff2_k<D>, dim3(B, D / TC_SLICE), dim3(TC_THREADS), 0, st, t);
+}
+
 // Last SelfAttBlock of a sampling step, from "at = x + A1(x)" (in ws.AT, statistics in ws.ST) on, evaluated only
 // for the row each sequence visits at this step (see gather_rows_k).  Result: ws.Xc [B, D] = block output rows.
 static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
@@ -1212,6 +1242,21 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
     if (att_x3(m, sg)) { p.A = ws.ATX; use_x3(p, w.a2.wqkvx, A / X3_BN); }     // column slice [A, ...) = n tiles from A / 128 on
     launch_gemm(m, p, false, false);
+    if (const int form = tail_form(m, B)) {        // everything behind the K projection in one or five launches (hd_tail_fused.hip.h)
+        TailP t{};
+        t.AT = ws.AT; t.Y = ws.Y; t.D = D; t.QKV = ws.QKV; t.ldq = 3 * A; t.A = A;
+        t.at_part = at_part; t.at_pw = at_pw; t.at_rows = at_rows;
+        t.wqkv = w.a2.wqkv; t.bqkv = w.a2.bqkv; t.wo = w.a2.wo; t.bo = w.a2.bo;
+        t.wf1 = w.wf1; t.bf1 = w.bf1; t.Fd = Fd; t.wf2 = w.wf2; t.bf2 = w.bf2;
+        t.rope_cos = m->rope_cos; t.rope_sin = m->rope_sin; t.order = ws.order; t.T = ws.T; t.Tmax = m->sTmax; t.rs = cur(m).rs;
+        t.Xc = ws.Xc; t.nhead = m->cfg.nhead; t.sg = sg;
+        t.head = m->head; t.tokens = ws.tokens; t.q_noise = m->s_has_q ? m->qnoise : nullptr; t.q_rows = m->sB; t.q_off = cur(m).row_off;
+        t.PW = ws.PW; t.OP = ws.YV; t.ATc = ws.ATc; t.F1c = ws.F1c;
+        if (form == TAIL_ONE) hipLaunchKernelGGL(tail_fused_k, dim3(B), dim3(TAIL_THREADS), 0, st, t);
+        else if (D == 768) launch_tail_sliced<768>(t, B, m->cfg.nhead, Fd, st);
+        else launch_tail_sliced<512>(t, B, m->cfg.nhead, Fd, st);
+        return;
+    }
     // visited rows of `at` and of the block input x
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.AT, D, ws.ATc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
     hipLaunchKernelGGL(gather_rows_k, dim3((B + 3) / 4), dim3(256), 0, st, ws.Y, D, ws.Xc, ws.order, ws.T, m->sTmax, cur(m).rs, sg);
@@ -1484,9 +1529,11 @@ static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, 
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = ln.ws;
     // the injected Exp(1) noise lives once, for the whole batch, in the model (m->qnoise)
-    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64 * SS_WAVES), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
-                       ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0);
-    hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
+    if (!(prune && tail_form(m, sg.B) == TAIL_ONE))   // (the one-kernel tail draws the token itself); its last workgroup advances the step
+        hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64 * SS_WAVES), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
+                           ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0, 1);
+    else
+        hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }

@@ -62,6 +62,7 @@ struct RunState {
     uint32_t pad[4];       // pad[0]: set by sample_step_k when a visited row had non-finite logits
                            // pad[1]: range guard of the split-precision kernels -- set by whoever writes an fp16 (hi, lo) split of
                            //         a value with |x| >= X16_LIMIT (hi would round to inf); the host re-runs on the fp32 kernels
+    uint32_t done;         // workgroups of sample_step_k that have finished this step: the last one advances `step` (no launch for it)
 };
 // fp16 holds |x| < 65520 before rounding to infinity; operands of the split-precision kernels are not scaled (see gemm_x3_k),
 // so every producer of a split checks its values against this and raises RunState::pad[1] (two v_max3_f32 per float4)
@@ -1879,7 +1880,8 @@ __global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_
         vph[par] = Vh + qi * (AX_VKEYS * 2) + (G::vpos(4 * par + g, qi) << 4);
         vpl[par] = vph[par] + AX_VPLANE;
     }
-    for (int qt = wave; qt < nqt; qt += NTH / 64) {
+    // (gridDim.y > 1: a few sequences -- the query tiles of a (sequence, head) are shared out over gridDim.y workgroups, each staging K and V)
+    for (int qt = wave + (NTH / 64) * blockIdx.y; qt < nqt; qt += (NTH / 64) * gridDim.y) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
         const long qrow = sg.row(b, qc);
@@ -2227,27 +2229,19 @@ __device__ __forceinline__ void ln_row_regs(const float* __restrict__ x, int D, 
     }
 }
 
-// Four waves per sequence: each normalises the row (the same arithmetic, so the same values) and takes the decoder rows
-// j = wave, wave + 4, ...; wave 0 then runs the softmax and the draw on the 22 logits (one wave per sequence with 22 serial
-// dot products was 103 us of latency per step).
-constexpr int SS_WAVES = 4;
-__global__ void __launch_bounds__(64 * SS_WAVES) sample_step_k(const float* __restrict__ Hm, int D, HeadW w,
-                                                     int32_t* __restrict__ tokens,
-                                                     const int32_t* __restrict__ order,
-                                                     const int32_t* __restrict__ T, int Tmax,
-                                                     const float* __restrict__ q_noise, int q_rows, int q_off,
-                                                     const RunState* __restrict__ rs, Segs sg, int compact) {
-    __shared__ float lg[32];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t t = rs->step;
-    if ((int)t >= T[b]) return;
-    const int slot = order[(long)b * Tmax + t];
+// NW waves per sequence: each normalises the row (the same arithmetic, so the same values) and takes the decoder rows
+// j = wave, wave + NW, ...; wave 0 then runs the softmax and the draw on the 22 logits (one wave per sequence with 22 serial
+// dot products was 103 us of latency per step).  x: the row (global or LDS); lg: 32 floats of LDS.  Called by every wave of the block.
+template <int NW>
+__device__ __forceinline__ void sample_row(const float* x, int D, const HeadW& w, int32_t* __restrict__ tokens, int b, int slot, uint32_t t,
+                                           const float* __restrict__ q_noise, int q_rows, int q_off, const RunState* __restrict__ rs, int L,
+                                           float* lg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float y[16];
-    // compact: Hm is [B, D] holding only the visited row of each sequence (pruned last block)
-    ln_row_regs(Hm + (compact ? (long)b : (long)sg.row(b, slot)) * D, D, lane, w, y);
+    ln_row_regs(x, D, lane, w, y);
 #pragma unroll
-    for (int jj = 0; jj < (22 + SS_WAVES - 1) / SS_WAVES; ++jj) {
-        const int j = wave + SS_WAVES * jj;
+    for (int jj = 0; jj < (22 + NW - 1) / NW; ++jj) {
+        const int j = wave + NW * jj;
         if (j < 22) {
             float a = 0.f;
 #pragma unroll
@@ -2285,7 +2279,35 @@ __global__ void __launch_bounds__(64 * SS_WAVES) sample_step_k(const float* __re
         int b2 = __shfl_xor(best, o);
         if (r2 > ratio || (r2 == ratio && b2 < best)) { ratio = r2; best = b2; }
     }
-    if (lane == 0) tokens[(long)b * sg.L + slot] = best;
+    if (lane == 0) tokens[(long)b * L + slot] = best;
+}
+
+// advance != 0: the last workgroup to finish moves rs->step on (every thread of the grid has read it by then), which saves the
+// one-thread launch per step that advance_step_k was.
+constexpr int SS_WAVES = 16;
+__global__ void __launch_bounds__(64 * SS_WAVES) sample_step_k(const float* __restrict__ Hm, int D, HeadW w,
+                                                     int32_t* __restrict__ tokens,
+                                                     const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ T, int Tmax,
+                                                     const float* __restrict__ q_noise, int q_rows, int q_off,
+                                                     RunState* __restrict__ rs, Segs sg, int compact, int advance) {
+    __shared__ float lg[32];
+    const int b = blockIdx.x;
+    const uint32_t t = __hip_atomic_load(&rs->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)t < T[b]) {
+        const int slot = order[(long)b * Tmax + t];
+        // compact: Hm is [B, D] holding only the visited row of each sequence (pruned last block)
+        sample_row<SS_WAVES>(Hm + (compact ? (long)b : (long)sg.row(b, slot)) * D, D, w, tokens, b, slot, t, q_noise, q_rows, q_off, rs, sg.L, lg);
+    } else {
+        __syncthreads();                                 // (sample_row has one: every wave has read the step before thread 0 goes on)
+    }
+    if (advance && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&rs->done, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(&rs->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rs->step, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Full decoder for hd_forward: logits[b, l, :] = Linear(LN(h[row(b,l)])) , one wave per (b, l).
@@ -2306,7 +2328,7 @@ __global__ void __launch_bounds__(256) decode_all_k(const float* __restrict__ Hm
     }
 }
 
-__global__ void set_step_k(RunState* rs, uint32_t step) { rs->step = step; }
+__global__ void set_step_k(RunState* rs, uint32_t step) { rs->step = step; rs->done = 0; }
 __global__ void advance_step_k(RunState* rs) { rs->step += 1; }
 
 }  // namespace hd

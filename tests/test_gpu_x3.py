@@ -369,6 +369,22 @@ def test_fused_token_encoder_kernel_matches_the_per_gemm_launches():
         assert f"tokens equal rows {B} of {B}" in out, out[-800:]
 
 
+def test_forms_of_the_pruned_tail_draw_the_same_tokens():
+    """hd_tail_fused.hip.h: the pruned tail of a sampling step as five sliced launches (HUDIFF_TAIL=2, the default for lanes of at most
+    64 sequences) or as one kernel per step (HUDIFF_TAIL=1, measured and not adopted) against the twelve separate launches
+    (HUDIFF_TAIL=0): complete samples, Philox and injected noise, must give the same tokens in every slot
+    (scripts/tail_fused_check.py runs the forms in child processes; the reference traces of test_prod_trace.py run on the default)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for kind, B, route, form in (("ab", 8, "split", "2"), ("nb", 16, "split", "2"), ("ab", 3, "f32_all", "2"), ("ab", 5, "split", "1")):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "tail_fused_check.py"), kind, str(B), route], capture_output=True, text=True,
+                           timeout=900, cwd=root, env=dict(os.environ, TAIL_A="0", TAIL_B=form))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        for k in ("tokens_philox", "tokens_noise"):
+            assert f"{kind} {B} {route} {k} rows with identical tokens {B} of {B} | differing slots 0 of" in r.stdout, r.stdout[-1200:]
+
+
 def test_whole_gpu_suite_with_all_fp32_as_process_default(tmp_path):
     """VERDICT r3 "Next" #1 (c): the outer suite runs the library default (split precision); here every -m gpu test runs once more in a
     process that has HUDIFF_PRECISION=f32_all exported, i.e. with the all-fp32 kernels as the default of every handle the suite
