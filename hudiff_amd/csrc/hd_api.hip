@@ -959,9 +959,31 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
             if (conv) hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, true, 3>), grid, dim3(512), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<256, 128, 4, 2, false, 3>), grid, dim3(512), 0, st, q);
         } else if (shape == 32) {
-            if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 2>), grid, dim3(256), 0, st, q);
-            else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 2>), grid, dim3(256), 0, st, q);
+            // few blocks per CU: the K loop is a chain of DMA round trips (~0.8 us per k tile, whatever the grid), so a third LDS stage --
+            // two tiles in flight, 60 KB, still two blocks per CU -- pays: B = 1 3.88 -> 4.60 sequences/s, B = 8 29.8 -> 32.8, B = 16
+            // 45.7 -> 46.8 (Nb: 8.47 -> 9.51, 64.7 -> 71.1, 120.6 -> 130.4).  Four stages (80 KB, one block per CU) gain less and lose
+            // from B = 16 on.  HUDIFF_X3_TINY_NS = 2 / 4 forces.
+            static const int ns = [] { const char* e = getenv("HUDIFF_X3_TINY_NS"); return e ? atoi(e) : 3; }();
+            if (ns == 3) {
+                if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 3>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 3>), grid, dim3(256), 0, st, q);
+            } else if (ns == 4) {
+                if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 4>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 4>), grid, dim3(256), 0, st, q);
+            } else {
+                if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 2>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 2>), grid, dim3(256), 0, st, q);
+            }
         } else if (shape == 64) {
+            // three stages (72 KB, still two blocks per CU) while the launch has at most one block per CU: B = 16 48.3 -> 51.4 sequences/s,
+            // Nb B = 32 200.4 -> 205.9; with 257 .. 384 blocks it gains in places (Nb B = 64 301 -> 317) and loses in others (B = 48
+            // 82.2 -> 78.1), so larger grids keep two stages.  HUDIFF_X3_SMALL_NS = 2 / 3 forces, HUDIFF_X3_SMALL_NS3_MAX moves the limit.
+            static const int ns64 = [] { const char* e = getenv("HUDIFF_X3_SMALL_NS"); return e ? atoi(e) : 0; }();
+            static const long ns3_max = [] { const char* e = getenv("HUDIFF_X3_SMALL_NS3_MAX"); return e ? atol(e) : 256L; }();
+            if (ns64 == 3 || (ns64 == 0 && (long)q.tiles_m * q.tiles_n <= ns3_max)) {
+                if (conv) hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, true, 3>), grid, dim3(256), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, false, 3>), grid, dim3(256), 0, st, q);
+            } else
             if (conv) hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);
         } else {

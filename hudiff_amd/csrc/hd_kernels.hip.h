@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void lds_barrier() {
 // (DMA-only ablation: 24 round trips per block); the big launches use three stages of 256 x 128 tiles (144 KB, one block of
 // eight waves per CU).
 template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS == 2) ? 2 : 1) gemm_x3_k(const GemmP p) {
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS <= 3) ? 2 : 1) gemm_x3_k(const GemmP p) {
     constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
