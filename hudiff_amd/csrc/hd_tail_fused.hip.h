@@ -1,14 +1,15 @@
-// hd_tail_fused.hip.h -- the pruned tail of a sampling step as ONE kernel (round 4).
+// hd_tail_fused.hip.h -- the pruned tail of a sampling step in fewer launches (round 4).
 //
 // After the last SelfAttBlock only the row each sequence visits at this step feeds the decoder (antibody_scripts/sample.py:508-513),
 // so from "at = x + A1(x)" on the block is evaluated for that one row per sequence (hd_api.hip, pruned_tail): query projection,
 // one-query attention against all keys, value side through the input rows, out-projection, feed-forward.  As separate launches that
 // is twelve tiny kernels (gathers, row statistics, four 1-row GEMMs, attn_row_k, row_value_k, head_proj_k) of 5-70 us each: 0.25 ms of
-// a 1.9 ms single-sequence step, 0.43 ms of a 256-row one, all of it launch and dependent-load latency.  Here: one workgroup of 1024
-// threads per sequence, every intermediate in LDS, the five vector-matrix products as column-pair GEMVs with the K range split over
-// thread groups (partial sums combined in a fixed order: deterministic), weights straight from L2.
+// a single-sequence step, all of it launch and dependent-load latency.  Two forms, both fp32 throughout, every sum in a fixed order:
+//   tail_fused_k            ONE workgroup of 1024 threads per sequence, every intermediate in LDS, the draw included (HUDIFF_TAIL=1).
+//                           Correct and NOT faster (205 us at B = 8): 7.5 MB of weights and rows per sequence through one CU.
+//   tail_pw_k ... tail_ff2_k  the same phases as five launches sliced over heads / 128-column slices (below): 46 us at B = 8.  The default
+//                           for lanes of at most 64 sequences (hd_api.hip, tail_form); larger lanes keep the separate launches.
 //   reference: model/encoder/cross_attention.py:149-173 (AttLayer), :273-287 (SelfAttBlock), restricted to one query row.
-// Same arithmetic as the separate kernels up to the association of the sums (fp32 throughout).
 #pragma once
 #include "hd_kernels.hip.h"
 
@@ -301,6 +302,7 @@ __device__ __forceinline__ bool tc_row(const TailP& p, int b, uint32_t& t, int& 
 
 template <int D>
 __global__ void __launch_bounds__(TC_THREADS, 1) tail_pw_k(const TailP p) {
+    static_assert(lds_fill_ok((D + 64 * 64 + 3 * 64) * 4, TC_THREADS), "LDS co-residency rule");
     __shared__ __attribute__((aligned(16))) float at_c[D];
     __shared__ __attribute__((aligned(16))) float red[64 * 64];
     __shared__ float qraw[64], qs[64], scratch[64];
@@ -359,6 +361,7 @@ __global__ void __launch_bounds__(TC_THREADS, 1) tail_pw_k(const TailP p) {
 
 template <int D>
 __global__ void __launch_bounds__(TC_THREADS, 1) tail_val_k(const TailP p) {
+    static_assert(lds_fill_ok((TAIL_MAXL * RV_MAX_HEADS + 16 * 4 * TC_SLICE + RV_MAX_HEADS * TC_SLICE) * 4, TC_THREADS), "LDS co-residency rule");
     __shared__ __attribute__((aligned(16))) float ps[TAIL_MAXL * RV_MAX_HEADS];             // [key][head]
     __shared__ __attribute__((aligned(16))) float part[16 * 4 * TC_SLICE];                  // [wave][4 heads][128]; later the GEMV's partial sums
     __shared__ __attribute__((aligned(16))) float yv[RV_MAX_HEADS * TC_SLICE];              // [head][128]
@@ -423,6 +426,7 @@ __global__ void __launch_bounds__(TC_THREADS, 1) tail_val_k(const TailP p) {
 
 template <int D>
 __global__ void __launch_bounds__(TC_THREADS, 1) tail_out_k(const TailP p) {
+    static_assert(lds_fill_ok((TAIL_MAXA + 33 * TC_SLICE) * 4, TC_THREADS), "LDS co-residency rule");
     __shared__ __attribute__((aligned(16))) float o[TAIL_MAXA];
     __shared__ __attribute__((aligned(16))) float red[32 * TC_SLICE];
     __shared__ float outc[TC_SLICE];
@@ -445,6 +449,7 @@ __global__ void __launch_bounds__(TC_THREADS, 1) tail_out_k(const TailP p) {
 
 template <int D>
 __global__ void __launch_bounds__(TC_THREADS, 1) tail_ff1_k(const TailP p) {
+    static_assert(lds_fill_ok((D + 64 * 64 + 2 * 64) * 4, TC_THREADS), "LDS co-residency rule");
     __shared__ __attribute__((aligned(16))) float at_c[D];
     __shared__ __attribute__((aligned(16))) float red[64 * 64];
     __shared__ float f1[64], scratch[64];
@@ -460,6 +465,7 @@ __global__ void __launch_bounds__(TC_THREADS, 1) tail_ff1_k(const TailP p) {
 
 template <int D>
 __global__ void __launch_bounds__(TC_THREADS, 1) tail_ff2_k(const TailP p) {
+    static_assert(lds_fill_ok((TAIL_MAXF + 33 * TC_SLICE) * 4, TC_THREADS), "LDS co-residency rule");
     __shared__ __attribute__((aligned(16))) float f1[TAIL_MAXF];
     __shared__ __attribute__((aligned(16))) float red[32 * TC_SLICE];
     __shared__ float outc[TC_SLICE];
