@@ -1585,7 +1585,7 @@ static HdStatus sample_begin_impl(HdModel* m, const int32_t* tokens, const int32
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_sample_begin: HD_DROPOUT_INJECT needs masks");
     // two concurrent half-batches unless the batch is small, masks are injected (their layout is per full batch)
     // or the caller asked for one lane
-    static const int lane_min_b = [] { const char* e = getenv("HUDIFF_LANE_MIN_B"); int v = e ? atoi(e) : 40; return v < 2 ? 2 : v; }();      // two lanes pay from ~40 rows on (B = 48: 68.6 -> 76.0 sequences/s; B = 32: 61.2 -> 59.6)
+    static const int lane_min_b = [] { const char* e = getenv("HUDIFF_LANE_MIN_B"); int v = e ? atoi(e) : 16; return v < 2 ? 2 : v; }();      // two lanes pay from 16 rows on since the small-launch latency work (B = 16: 50.8 -> 52.9 sequences/s, B = 24: 57.7 -> 62.1, B = 32: 69.9 -> 72.4; B = 8 loses: 33.1 -> 30.6); 40 before it
     m->nlanes = (B >= lane_min_b && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? lanes_default() : 1;
     if (m->nlanes > B) m->nlanes = B;
     for (int l = 0, off = 0; l < m->nlanes; ++l) {            // balanced contiguous row blocks

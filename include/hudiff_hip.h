@@ -72,7 +72,7 @@ enum {
     HD_NO_GRAPH         = 4u,  /* launch kernels eagerly instead of replaying the captured hipGraph */
     HD_NO_PRUNE         = 8u,  /* hd_sample: evaluate the last attention block for every row (as hd_forward
                                   does) instead of only for the row each sequence visits at that step      */
-    HD_ONE_LANE         = 16u, /* hd_sample: keep the batch on one stream (default: batches >= 40 rows are
+    HD_ONE_LANE         = 16u, /* hd_sample: keep the batch on one stream (default: batches >= 16 rows are
                                   split into two halves that run concurrently on two streams)              */
     HD_LOOP_GRAPH       = 32u  /* hd_sample / hd_sample_run: the whole T-step loop of a lane is ONE hipGraph (a chain
                                   of T child-graph nodes of the captured step) launched once, instead of T replays
