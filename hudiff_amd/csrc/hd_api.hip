@@ -962,14 +962,11 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
             // few blocks per CU: the K loop is a chain of DMA round trips (~0.8 us per k tile, whatever the grid), so a third LDS stage --
             // two tiles in flight, 60 KB, still two blocks per CU -- pays: B = 1 3.88 -> 4.60 sequences/s, B = 8 29.8 -> 32.8, B = 16
             // 45.7 -> 46.8 (Nb: 8.47 -> 9.51, 64.7 -> 71.1, 120.6 -> 130.4).  Four stages (80 KB, one block per CU) gain less and lose
-            // from B = 16 on.  HUDIFF_X3_TINY_NS = 2 / 4 forces.
+            // from B = 16 on (instantiation removed).  HUDIFF_X3_TINY_NS = 2 restores two stages.
             static const int ns = [] { const char* e = getenv("HUDIFF_X3_TINY_NS"); return e ? atoi(e) : 3; }();
             if (ns == 3) {
                 if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 3>), grid, dim3(256), 0, st, q);
                 else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 3>), grid, dim3(256), 0, st, q);
-            } else if (ns == 4) {
-                if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 4>), grid, dim3(256), 0, st, q);
-                else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 4>), grid, dim3(256), 0, st, q);
             } else {
                 if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 2>), grid, dim3(256), 0, st, q);
                 else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 2>), grid, dim3(256), 0, st, q);
