@@ -964,6 +964,15 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
             // 45.7 -> 46.8 (Nb: 8.47 -> 9.51, 64.7 -> 71.1, 120.6 -> 130.4).  Four stages (80 KB, one block per CU) gain less and lose
             // from B = 16 on (instantiation removed).  HUDIFF_X3_TINY_NS = 2 restores two stages.
             static const int ns = [] { const char* e = getenv("HUDIFF_X3_TINY_NS"); return e ? atoi(e) : 3; }();
+            // ... with four extra waves per block that only issue the operand DMA (gemm_x3_k, LW): the five DMA instructions per k tile and
+            // the chain of six dependent MFMAs then run in different waves (B = 1 4.61 -> 4.92 sequences/s, B = 8 33.3 -> 34.4, Nb B = 8
+            // 72.4 -> 77.0).  Such a block takes a CU alone (512 threads, 146 registers), so only while all lanes' blocks of the launch
+            // fit one per CU (B = 16 on two lanes: 52.3 -> 49.5 otherwise).  HUDIFF_X3_LOADERS=0 switches them off.
+            static const int loaders = [] { const char* e = getenv("HUDIFF_X3_LOADERS"); return e ? atoi(e) : 1; }();
+            if (loaders && ns == 3 && (long)q.tiles_m * q.tiles_n * (m->in_session ? m->nlanes : 1) <= 256) {
+                if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 3, 4>), grid, dim3(512), 0, st, q);
+                else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 3, 4>), grid, dim3(512), 0, st, q);
+            } else
             if (ns == 3) {
                 if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 3>), grid, dim3(256), 0, st, q);
                 else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 3>), grid, dim3(256), 0, st, q);
@@ -1442,7 +1451,7 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 // split-precision kernels (whole path or attention only) currently in use / switched off for good by the range guard
 static bool split_active(const HdModel* m) { return (m->x3 || m->attn_x3) && !m->x3_suspended; }
 // which kernels a captured step graph holds: split kernels in use, ln_sync level
-static int kernel_set(const HdModel* m) { return (split_active(m) ? 1 : 0) | (m->lnsync_level << 1); }
+static int kernel_set(const HdModel* m) { return (split_active(m) ? 1 : 0) | (m->lnsync_level << 1) | (m->nlanes << 4); }       // (the lane count picks kernels too: launch_gemm)
 static void suspend_split(HdModel* m) {
     // said once per handle (stderr; HUDIFF_QUIET=1 silences it): from here on the handle runs the all-fp32 kernels, at their speed
     static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();

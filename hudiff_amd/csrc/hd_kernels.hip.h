@@ -1048,9 +1048,13 @@ __device__ __forceinline__ void lds_barrier() {
 // under load -- four times the MFMA time of a 128 x 128 x 32 tile -- so with two stages the loop is bound by that latency
 // (DMA-only ablation: 24 round trips per block); the big launches use three stages of 256 x 128 tiles (144 KB, one block of
 // eight waves per CU).
-template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS <= 3) ? 2 : 1) gemm_x3_k(const GemmP p) {
-    constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * NW;
+// LW > 0: LW extra waves per block that only issue the operand DMA (waves NW .. NW + LW - 1), while the NW MFMA waves issue none: in the
+// small launches a wave's five DMA instructions per k tile (~0.2 us of issue) and its chain of six dependent MFMAs (~0.1 us) are otherwise
+// serial in the same wave.  LW must equal NW (the piece -> wave mapping is the MFMA waves' own).
+template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2, int LW = 0>
+__global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 && LW == 0) ? 2 : 1) gemm_x3_k(const GemmP p) {
+    static_assert(LW == 0 || LW == WM * WN, "loader waves mirror the MFMA waves");
+    constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * (NW + LW);
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
     constexpr int EPI_FLOATS = NW * 32 * ES, PART_FLOATS = NW * WTM * 2;
@@ -1068,7 +1072,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS <= 3) ? 2 : 
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     char* St = reinterpret_cast<char*>(smem);          // stage s at St + s * STAGE_BYTES: A hi, A lo, W hi, W lo
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave_all >= NW;      // (wave-uniform)
+    const int wave = loader ? wave_all - NW : wave_all;
     const int wm = wave / WN, wn = wave % WN;
     int bx, by, seg = 0;
     {
@@ -1209,23 +1215,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NS <= 3) ? 2 : 
     constexpr int PER_TILE = A_PIECES + W_PIECES, KEEP = (NS - 2) * PER_TILE;
     static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
     constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
+    const bool does_dma = LW == 0 || loader, does_mma = LW == 0 || !loader;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < nkt) dma(t, t);
+        if (t < nkt && does_dma) dma(t, t);
     if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
     lds_barrier();
     int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = kt + NS - 1 < nkt;
         // stage st_in was read in tile kt-1; every wave is past the barrier that ended that tile
-        if (more && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
-        if (abl_mode != 1 && abl_mode != 3) mma(st);
+        if (more && does_dma && abl_mode != 2 && abl_mode != 3) dma(kt + NS - 1, st_in);
+        if (does_mma && abl_mode != 1 && abl_mode != 3) mma(st);
         // tile kt+1 must have landed before the next iteration reads it ...
         if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
         lds_barrier();                                 // ... everybody's part of it; everybody is done reading tile kt
         st_in = st;
         st = st + 1 == NS ? 0 : st + 1;
     }
+    if (LW > 0 && loader) return;                      // (the epilogue's barriers count the waves that are left)
     if (p.x3_abl & 8) {                                // probe: no epilogue (the accumulators stay live through a never-true store)
         float s = 0.f;
 #pragma unroll
