@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Repeated complete samples at small batches (the three-stage small tiles, the sliced tail, the self-advancing draw): every repetition of a
+"""Repeated complete samples at small batches (the three-stage small tiles with loader waves, the sliced tail, the self-advancing draw): every repetition of a
 batch size must give the same tokens, and the same tokens as the separate-launch / two-stage settings of a child process.
     python scripts/small_soak.py [ab|nb] [reps]"""
 import hashlib, os, subprocess, sys
@@ -29,6 +29,6 @@ if __name__ == "__main__":
     if os.environ.get("SMALL_SOAK_CHILD"):
         run(kind, reps)
         sys.exit(0)
-    for name, env in (("default", {}), ("two stages, separate tail launches, one attention workgroup", dict(HUDIFF_X3_TINY_NS="2", HUDIFF_X3_SMALL_NS="2", HUDIFF_TAIL="0", HUDIFF_ATTN_QSPLIT_MAX="0"))):
+    for name, env in (("default", {}), ("two stages, no loader waves, separate tail launches, one attention workgroup", dict(HUDIFF_X3_TINY_NS="2", HUDIFF_X3_SMALL_NS="2", HUDIFF_X3_LOADERS="0", HUDIFF_TAIL="0", HUDIFF_ATTN_QSPLIT_MAX="0"))):
         print("settings:", name, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), kind, str(reps if not env else 2)], env=dict(os.environ, SMALL_SOAK_CHILD="1", **env), check=True)
