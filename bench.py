@@ -230,6 +230,24 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
 PEAK_F16_MATRIX_TFLOPS = 2500.0    # same guide, dense fp16 MFMA; three fp16 MFMAs per fp32 product -> 833.3 fp32-equivalent
 
 
+GUARD_INVALIDATED = []          # (route, sample) whose tokens a guard of the split kernels invalidated (reported in precision_evidence)
+
+
+def tokens_of_sample(model, shape, tag):
+    """Tokens of the sample just timed (hd_sample_tokens).  A range / ln_sync guard that fired during that sample makes the library refuse
+    them (HD_ERR_STATE: only hd_sample_end repeats a sample); the handle has already switched to the safe kernels (hd_sync looked at the
+    flags), so the benchmark goes on: the sample is marked invalid (-1 everywhere) and listed, instead of aborting the run."""
+    from hudiff_amd._lib import HD_ERR_STATE, HudiffError
+    try:
+        return model.sample_tokens()
+    except HudiffError as e:
+        if e.status != HD_ERR_STATE:
+            raise
+        GUARD_INVALIDATED.append(tag)
+        sys.stderr.write(f"[bench] {tag}: a guard of the split kernels fired during this sample; its tokens are not used ({e})\n")
+        return np.full(shape, -1, dtype=np.int32)
+
+
 def timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, precision, steps, warmup, first_key=0, keep_tokens=True):
     """One timed leg of a workload beside the top-level line: a model on route `precision` (hd_set_precision), the same protocol
     as the main line (inputs resident, restart + all T steps per sample, device sync on both sides, HIP-event time of the
@@ -253,7 +271,7 @@ def timed_leg(args, kind, cfg, sd, batch, T, rank, local_rank, precision, steps,
             model.sync()
             gpu_ms += model.last_run_ms()[0]
             if keep_tokens:
-                toks.append(model.sample_tokens())
+                toks.append(tokens_of_sample(model, batch["tokens"].shape, f"{kind}/{precision}/sample {i}"))
     elapsed = time.perf_counter() - t0
     clock_power = watch.stop() if watch else None
     last = model.sample_end()
@@ -501,7 +519,7 @@ def main():
         if timed:
             model.sync()
             gpu_ms += model.last_run_ms()[0]
-            main_tokens.append(model.sample_tokens())    # 300 KB device-to-host after the sync: < 0.01 % of a sample
+            main_tokens.append(tokens_of_sample(model, batch["tokens"].shape, f"main/sample {i}"))    # 300 KB device-to-host after the sync: < 0.01 % of a sample
 
     for i in range(args.warmup):
         one_sample(-1 - i, False)
@@ -530,8 +548,10 @@ def main():
     def agreement(a, b):
         """rows with identical final tokens, over every timed sample both legs ran with the same noise keys"""
         n = min(len(a), len(b))
-        same = int((np.asarray(a[-n:]) == np.asarray(b[-n:])).all(-1).sum())
-        return {"rows_identical": same, "rows_compared": int(n * B), "samples_compared": int(n)}
+        a, b = np.asarray(a[-n:]), np.asarray(b[-n:])
+        ok = (a >= 0).all((1, 2)) & (b >= 0).all((1, 2))          # samples a guard invalidated (tokens_of_sample) are left out
+        same = int((a[ok] == b[ok]).all(-1).sum())
+        return {"rows_identical": same, "rows_compared": int(ok.sum() * B), "samples_compared": int(ok.sum())}
 
     all_fp32, fp32_tokens = None, None
     if rank == 0 and not only_main and not args.no_all_fp32_line and route_main != "f32_all":
@@ -706,6 +726,8 @@ def main():
         if f32_gemm is not None:
             out["f32_gemm_route"] = f32_gemm
         if evidence is not None:
+            if GUARD_INVALIDATED:
+                evidence["samples_invalidated_by_a_guard"] = list(GUARD_INVALIDATED)
             out["precision_evidence"] = evidence
         if secondary is not None:
             out["secondary"] = {"hudiff_nb_configs3": secondary}

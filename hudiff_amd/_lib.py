@@ -27,7 +27,14 @@ EXPORTS = [
     "hd_forward", "hd_sample", "hd_sample_begin", "hd_sample_run", "hd_sample_restart", "hd_sample_end", "hd_sync",
     "hd_last_run_ms", "hd_flops_per_row_forward", "hd_flops_per_row_sample_step", "hd_device_info", "hd_debug_stop_after", "hd_debug_read", "hd_precision_info",
     "hd_set_precision", "hd_precision_report", "hd_precision_reset", "hd_sample_tokens", "hd_debug_fail_next_lnsync",
+    "hd_set_option", "hd_get_option", "hd_debug_scatter_lnsync",
 ]
+
+# tuning options (include/hudiff_hip.h, HdOption): name -> id; the names are the enum's, lower case without the HD_OPT_ prefix
+OPTIONS = {n: i for i, n in enumerate((
+    "lanes", "lane_min_rows", "split_min_rows", "big_min_rows", "lnsync_level", "tail_form", "tail_max_rows", "small_grid", "tiny_grid",
+    "loader_waves", "tiny_stages", "small_stages", "small_stages3_max_grid", "attn_qsplit_max_grid", "attn_waves", "loop_graph",
+    "prune_value_via_rows", "split_tile", "gemm_small_tiles", "store_nt", "split_layer_mask", "split_attn", "fused_attn", "fused_attn_min_grid"))}
 
 
 class HdConfig(C.Structure):
@@ -93,6 +100,9 @@ def load():
     lib.hd_precision_report.argtypes = [vp, P(HdPrecisionInfo), C.c_size_t]
     lib.hd_precision_reset.argtypes = [vp]
     lib.hd_debug_fail_next_lnsync.argtypes = [vp]
+    lib.hd_set_option.argtypes = [vp, C.c_int32, C.c_int64]
+    lib.hd_get_option.argtypes = [vp, C.c_int32, P(C.c_int64)]
+    lib.hd_debug_scatter_lnsync.argtypes = [vp, C.c_int32]
     lib.hd_debug_stop_after.argtypes = [vp, C.c_int32]
     lib.hd_debug_read.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64]
     _lib = lib

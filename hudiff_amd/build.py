@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhudiff_hip.so")
 SOURCES = [os.path.join(CSRC, "hd_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"), os.path.join(CSRC, "hd_enc_fused.hip.h"), os.path.join(CSRC, "hd_tail_fused.hip.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"), os.path.join(CSRC, "hd_tail_fused.hip.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hudiff_hip.h")]
 
 

@@ -7,8 +7,8 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails with HD_ERR_NO_DEVICE.
 #include "../../include/hudiff_hip.h"
 #include "hd_kernels.hip.h"
-#include "hd_enc_fused.hip.h"
 #include "hd_tail_fused.hip.h"
+#include "hd_attn_fused.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -96,23 +96,45 @@ struct Workspace {
 };
 
 constexpr int HD_MAX_LANES = 4;
-// Launches of at least this many activation rows take the big-launch kernels (128-row tiles, split precision where the route has
-// it); smaller ones the generic 32 x 128 fp32 kernels.  HUDIFF_BIG_ROWS: tuning aid (default 8192).
-static long big_rows() {
-    static long n = [] { const char* e = getenv("HUDIFF_BIG_ROWS"); long v = e ? atol(e) : 8192; return v < 1 ? 1 : v; }();
-    return n;
-}
-// Split-precision launches pay from a single sequence on: with tiles sized to the grid (launch_gemm: 64 x 128 / 32 x 128 tiles for
-// under-filled grids) the split kernels beat the generic fp32 ones at every batch size (round 4 sweeps, profiles/r04/small_batch_*.txt:
-// B = 1 antibody 2.65 -> 3.45 sequences/s, B = 8 17.6 -> 26.2, B = 16 25.2 -> 41.2, B = 24 29.6 -> 48; the fp32 big-launch kernels gain
-// nothing below 8192 rows).  HUDIFF_X3_ROWS: tuning aid (default 128).
-static long x3_rows() {
-    static long n = [] { const char* e = getenv("HUDIFF_X3_ROWS"); long v = e ? atol(e) : 128; return v < 1 ? 1 : v; }();
-    return n;
-}
-static int lanes_default() {
-    static int n = [] { const char* e = getenv("HUDIFF_LANES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > HD_MAX_LANES ? HD_MAX_LANES : v); }();
-    return n;
+
+// ---- tuning options (include/hudiff_hip.h "tuning options") -----------------------------------------------------------------------
+// One table: id, the environment variable that overrides the DEFAULT of an option nobody set, default, legal range (`set` = the
+// legal values when they are not a range), `create_only` = fixed at hd_finalize.  hd_create fills HdModel::opt from it.
+struct OptDef { int id; const char* env; int64_t def, lo, hi; int64_t set[4]; int nset; bool create_only; };
+constexpr int64_t OPT_BIG = (int64_t)1 << 40;
+static const OptDef OPTS[HD_OPT_COUNT] = {
+    {HD_OPT_LANES, "HUDIFF_LANES", 2, 1, HD_MAX_LANES, {}, 0, false},
+    {HD_OPT_LANE_MIN_ROWS, "HUDIFF_LANE_MIN_B", 16, 2, OPT_BIG, {}, 0, false},      // two lanes pay from 16 rows on (round 4 sweeps: B = 16 50.8 -> 52.9 sequences/s; B = 8 loses 8 %)
+    {HD_OPT_SPLIT_MIN_ROWS, "HUDIFF_X3_ROWS", 128, 1, OPT_BIG, {}, 0, false},       // the split kernels pay from a single sequence on (tiles sized to the grid, launch_gemm)
+    {HD_OPT_BIG_MIN_ROWS, "HUDIFF_BIG_ROWS", 8192, 1, OPT_BIG, {}, 0, false},       // the fp32 big-launch kernels gain nothing below 8192 rows
+    {HD_OPT_LNSYNC_LEVEL, "HUDIFF_X3_LNSYNC", 2, 0, 2, {}, 0, false},
+    {HD_OPT_TAIL_FORM, "HUDIFF_TAIL", 2, 0, 2, {0, 2}, 2, false},
+    {HD_OPT_TAIL_MAX_ROWS, "HUDIFF_TAIL_MAX_B", 64, 0, OPT_BIG, {}, 0, false},
+    {HD_OPT_SMALL_GRID, "HUDIFF_X3_SMALL_GRID", 300, 0, OPT_BIG, {}, 0, false},     // B = 8 antibodies 20.0 -> 25.1 sequences/s, B = 16 36.5 -> 42.4, B = 48 73.3 -> 78.4; larger limits lose again
+    {HD_OPT_TINY_GRID, "HUDIFF_X3_TINY_GRID", 150, 0, OPT_BIG, {}, 0, false},
+    {HD_OPT_LOADER_WAVES, "HUDIFF_X3_LOADERS", 1, 0, 1, {}, 0, false},
+    {HD_OPT_TINY_STAGES, "HUDIFF_X3_TINY_NS", 3, 2, 3, {}, 0, false},
+    {HD_OPT_SMALL_STAGES, "HUDIFF_X3_SMALL_NS", 0, 0, 3, {0, 2, 3}, 3, false},
+    {HD_OPT_SMALL_STAGES3_MAX_GRID, "HUDIFF_X3_SMALL_NS3_MAX", 256, 0, OPT_BIG, {}, 0, false},
+    {HD_OPT_ATTN_QSPLIT_MAX_GRID, "HUDIFF_ATTN_QSPLIT_MAX", 128, 0, OPT_BIG, {}, 0, false},
+    {HD_OPT_ATTN_WAVES, "HUDIFF_ATTN_WAVES", 12, 8, 12, {8, 12}, 2, false},
+    {HD_OPT_LOOP_GRAPH, "HUDIFF_LOOP_GRAPH", 0, 0, 1, {}, 0, false},
+    {HD_OPT_PRUNE_VALUE_VIA_ROWS, "HUDIFF_PRUNE_V", 1, 0, 1, {}, 0, false},
+    {HD_OPT_SPLIT_TILE, "HUDIFF_X3_TILE", 0, 0, 512, {0, 128, 256, 512}, 4, false},
+    {HD_OPT_GEMM_SMALL_TILES, "HUDIFF_GEMM_SMALL", 1536, 0, OPT_BIG, {}, 0, false},
+    {HD_OPT_STORE_NT, "HUDIFF_ST_NT", 0, 0, 1, {}, 0, false},
+    {HD_OPT_SPLIT_LAYER_MASK, "HUDIFF_X3_MASK", 3, 0, 3, {}, 0, true},
+    {HD_OPT_SPLIT_ATTN, "HUDIFF_X3_ATTN", 1, 0, 1, {}, 0, false},
+    {HD_OPT_FUSED_ATTN, "HUDIFF_FUSED_ATTN", 1, 0, 1, {}, 0, false},
+    // one workgroup per (sequence, head group): with fewer than ~half the CUs busy the two-launch form's finer tiles win (round 5 sweep,
+    // profiles/r05: antibodies B = 8 30.9 vs 34.1 sequences/s, B = 16 52.1 vs 51.4, B = 64 89.0 vs 85.1; nanobodies B = 16 129 vs 138, B = 64 322 vs 293)
+    {HD_OPT_FUSED_ATTN_MIN_GRID, "HUDIFF_FUSED_ATTN_MIN_GRID", 128, 0, OPT_BIG, {}, 0, false},
+};
+static bool opt_legal(const OptDef& d, int64_t v) {
+    if (v < d.lo || v > d.hi) return false;
+    if (d.nset == 0) return true;
+    for (int i = 0; i < d.nset; ++i) if (d.set[i] == v) return true;
+    return false;
 }
 
 struct HdModel {
@@ -130,6 +152,8 @@ struct HdModel {
     // Precision route (include/hudiff_hip.h "precision routes"): what the caller asked for (hd_set_precision; DEFAULT = the library
     // default unless the environment of hd_finalize overrides it) and what hd_finalize resolved it to.
     int precision_req = HD_PRECISION_DEFAULT, precision = HD_PRECISION_SPLIT;
+    int64_t opt[HD_OPT_COUNT] = {};                  // tuning options (OPTS; hd_set_option / hd_get_option)
+    bool debug_lnsync_scatter = false;               // hd_debug_scatter_lnsync: the N tiles of an ln_sync M tile go to different XCDs
     bool x3 = false;                  // split-precision GEMMs (weight images built)
     // Range guard of the split-precision kernels: their fp16 (hi, lo) operands are not scaled, so a producer that meets
     // |x| >= 65504 raises RunState::pad[1]; the forward / sample is then re-run on the fp32 kernels and the model stays on
@@ -150,7 +174,7 @@ struct HdModel {
     SideW sidew{};
     const float *pos_w1 = nullptr, *pos_b1 = nullptr, *pos_w2 = nullptr, *pos_b2 = nullptr;
     HeadW head{};
-    const float *rope_cos = nullptr, *rope_sin = nullptr;
+    const float *rope_cos = nullptr, *rope_sin = nullptr, *rope_cs = nullptr;      // [L, 32] cos, sin; the same interleaved [L, 32, 2]
     float* side_vec = nullptr;
     float2* emb_stats = nullptr;      // [n_tokens] LayerNorm (mean, rstd) of each embedding row
     // injected Exp(1) noise of the open session, [Tmax, B, 22] for the WHOLE batch (every lane indexes it by its row
@@ -284,6 +308,14 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
         return fail(HD_ERR_NO_DEVICE, "hd_create: device %d is %s, kernels are built for gfx950 only", device, prop.gcnArchName);
     HdModel* m = new HdModel();
     m->cfg = c;
+    for (const OptDef& d : OPTS) {                   // library default, or the environment's override of the default (if legal)
+        m->opt[d.id] = d.def;
+        if (const char* e = getenv(d.env)) {
+            const int64_t v = atoll(e);
+            if (opt_legal(d, v)) m->opt[d.id] = v;
+            else if (d.nset == 0) m->opt[d.id] = v < d.lo ? d.lo : d.hi;        // out of range: clamped (as rounds 1-4 did)
+        }
+    }
     m->device = device;
     m->nseg = c.kind == HD_KIND_ANTIBODY ? 2 : 1;
     m->d = c.d_model; m->dh = c.d_model / 2; m->D = c.sum_d_model; m->Dh = c.sum_d_model / 2;
@@ -567,12 +599,11 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         // attention core of launches >= 8192 activation rows: attn_x3_k (S = K Q^T and O = V^T P^T as three fp16 MFMAs per product
         // on fp16 (hi, lo) splits of the fp32 Q, K, V, P; fp32 accumulation and softmax) on every route but F32_ALL
         m->attn_x3 = m->precision != HD_PRECISION_F32_ALL;
-        const char* e = getenv("HUDIFF_X3_LNSYNC");
-        m->lnsync_level_cfg = m->lnsync_level = e ? atoi(e) : 2;
+        m->lnsync_level_cfg = m->lnsync_level = (int)m->opt[HD_OPT_LNSYNC_LEVEL];
     }
     X3Packer* xp = m->x3 ? &xpk : nullptr;
-    // HUDIFF_X3_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
-    const int x3_mask = [] { const char* e = getenv("HUDIFF_X3_MASK"); return e ? atoi(e) : 3; }();
+    // HD_OPT_SPLIT_LAYER_MASK (ablation aid): 1 = ByteNet blocks, 2 = attention blocks take the split-precision kernels
+    const int x3_mask = (int)m->opt[HD_OPT_SPLIT_LAYER_MASK];
     X3Packer* xp_bn = (x3_mask & 1) ? xp : nullptr;
     X3Packer* xp_at = (x3_mask & 2) ? xp : nullptr;
     const bool ab = c.kind == HD_KIND_ANTIBODY;
@@ -666,7 +697,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     { auto t = ld.get("decoder.weight", {c.n_tokens, D}); h_w = pk.add(t ? t->data : std::vector<float>((size_t)c.n_tokens * D)); }
     h_bias = pk.add(ld.vec("decoder.bias", c.n_tokens));
     // RoPE table (cross_attention.py:35-56): angle = t * theta^(-2k/hd), float32 like torch
-    size_t o_cos, o_sin;
+    size_t o_cos, o_sin, o_cs;
     {
         std::vector<float> cs((size_t)L * 32), sn((size_t)L * 32);
         if (m->host.count("rope")) {
@@ -683,6 +714,9 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
             }
         }
         o_cos = pk.add(cs); o_sin = pk.add(sn);
+        std::vector<float> csi((size_t)L * 64);
+        for (size_t i = 0; i < (size_t)L * 32; ++i) { csi[2 * i] = cs[i]; csi[2 * i + 1] = sn[i]; }
+        o_cs = pk.add(csi);
     }
     if (!ld.err.empty()) return fail(HD_ERR_STATE, "hd_finalize: %s", ld.err.c_str());
     for (auto& kv : m->host)
@@ -727,7 +761,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     m->pos_w1 = B0 + p_w1; m->pos_b1 = B0 + p_b1; m->pos_w2 = B0 + p_w2; m->pos_b2 = B0 + p_b2;
     if (ab) m->sidew = {B0 + s_emb, B0 + s_w1, B0 + s_b1, B0 + s_lg, B0 + s_lb, B0 + s_w2, B0 + s_b2};
     m->head = {B0 + h_g, B0 + h_b, B0 + h_w, B0 + h_bias};
-    m->rope_cos = B0 + o_cos; m->rope_sin = B0 + o_sin;
+    m->rope_cos = B0 + o_cos; m->rope_sin = B0 + o_sin; m->rope_cs = B0 + o_cs;
     for (auto& ln : m->lane) {
         HIP_TRY(hipMalloc(&ln.rs, sizeof(RunState)));
         HIP_TRY(hipMemset(ln.rs, 0, sizeof(RunState)));
@@ -748,6 +782,8 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<19, AX19_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    HIP_TRY(hipFuncSetAttribute((const void*)qkv_attn_x3_k<19, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    HIP_TRY(hipFuncSetAttribute((const void*)qkv_attn_x3_k<10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     static_assert(lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS) <= LDS_PER_CU && lds_safe_request(AxGeom<10>::SMEM, ATT_THREADS) <= LDS_PER_CU, "LDS co-residency rule");
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
@@ -816,7 +852,7 @@ static GemmP base_gemm(const HdModel* m, const Segs& sg) {
 // caller BEFORE it asks the producer for split rows -- x3_use() holds every condition launch_gemm checks again.
 static bool x3_use(const HdModel* m, const Segs& sg, const X3W& x) {
     const long rows = (long)sg.B * sg.L, widest = 3L * m->A > m->D ? 3L * m->A : m->D;       // 32-bit byte offsets in every operand
-    return m->x3 && !m->x3_suspended && x.w && rows >= x3_rows() && rows * widest * 4 < (1L << 31);
+    return m->x3 && !m->x3_suspended && x.w && rows >= m->opt[HD_OPT_SPLIT_MIN_ROWS] && rows * widest * 4 < (1L << 31);
 }
 static void use_x3(GemmP& p, const X3W& x, int ntile0 = 0) {
     p.Wx = x.w + (long)ntile0 * x.ntile_stride; p.wx_stride = x.seg_stride; p.acc_scale = x.acc_scale;
@@ -828,11 +864,6 @@ static int gemm_bk() {
     return bk;
 }
 
-// HUDIFF_GEMM_NBUF=2: two LDS buffers, one barrier per k tile (tuning aid)
-static int gemm_nbuf() {
-    static int nb = [] { const char* e = getenv("HUDIFF_GEMM_NBUF"); return (e && atoi(e) == 2) ? 2 : 1; }();
-    return nb;
-}
 
 template <int BM, int BN, int WM, int WN, int BKT, int NB = 1>
 static void launch_gemm_t(GemmP& p, bool conv, bool per_seg, hipStream_t st) {
@@ -897,16 +928,15 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
     Workspace& ws = cur(m).ws;
     hipStream_t st = cur(m).stream;
     const long rows = (long)p.sg.B * p.sg.L;
-    const bool big = rows >= big_rows() || p.Wx != nullptr;      // (split-precision launches: x3_use() decided)
+    const bool big = rows >= m->opt[HD_OPT_BIG_MIN_ROWS] || p.Wx != nullptr;      // (split-precision launches: x3_use() decided)
     int pw = big ? 64 : 32;                              // column-slice width of the LayerNorm partials this launch leaves (its waves' WTN)
     p.part_rows = rows;
     // non-temporal epilogue stores: +0.9 % on the split-precision sample (3 x 3 interleaved runs; gemm_x3_k always uses them),
-    // nothing on the fp32 one (HUDIFF_ST_NT=1 turns them on there)
-    static const int st_nt = [] { const char* e = getenv("HUDIFF_ST_NT"); return e ? atoi(e) : 0; }();
-    p.st_nt = big ? st_nt : 0;
+    // nothing on the fp32 one (HD_OPT_STORE_NT turns them on there)
+    p.st_nt = big ? (int)m->opt[HD_OPT_STORE_NT] : 0;
     if (stats_out != STATS_NONE || apply || p.ln_sync) p.part = ws.PART[ws.part_next];
     if (p.ln_sync) p.sync_ctr = ws.SYNC;
-    static const int small_tiles = [] { const char* e = getenv("HUDIFF_GEMM_SMALL"); return e ? atoi(e) : 1536; }();
+    const long small_tiles = m->opt[HD_OPT_GEMM_SMALL_TILES];
     const long tiles128 = ((rows + 127) / 128) * ((p.N + 127) / 128);
     // the BK = 16 kernels assume whole k tiles and 32-bit byte offsets inside every operand (gemm_k, FAST)
     const long lda = p.lda, ldw = p.ldw ? p.ldw : p.N;
@@ -929,23 +959,23 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         GemmP q = p;
         q.sg = run;
         static const int abl = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e ? atoi(e) : 0; }();
-        q.x3_abl = abl | ((m->debug_lnsync_fail && q.ln_sync) ? 128 : 0);
+        q.x3_abl = abl | ((m->debug_lnsync_fail && q.ln_sync) ? 128 : 0) | ((m->debug_lnsync_scatter && q.ln_sync) ? 256 : 0);
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
         // tile shape / pipeline depth, by measurement: 256 x 256 tiles (two stages, one 8-wave block per CU)
         // for the widest output (Q|K|V, N = 1536: 621 vs 650 us), two stages of 128 x 128 tiles (two blocks per CU) elsewhere; three
-        // stages of 256 x 128 tiles were no faster anywhere (640 us).  HUDIFF_X3_TILE forces 128 / 256 (x 128, three stages) / 512 (= 256 x 256)
-        static const int force = [] { const char* e = getenv("HUDIFF_X3_TILE"); return e ? atoi(e) : 0; }();
+        // stages of 256 x 128 tiles were no faster anywhere (640 us).  HD_OPT_SPLIT_TILE forces 128 / 256 (x 128, three stages) / 512 (= 256 x 256)
+        const int force = (int)m->opt[HD_OPT_SPLIT_TILE];
         const long t256 = (rows0 + 255) / 256 + (rows1 + 255) / 256;
         int shape = (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) ? 512 : 128;
         if (force == 128 || force == 256 || (force == 512 && q.N % 256 == 0)) shape = force;
         if (q.ln_sync) shape = 128;                     // the meeting epilogue exists in the 4-wave 128 x 128 instantiation only
         // under-filled grids (mid-size batches): 64 x 128 tiles double the blocks of a launch whose 128 x 128 grid leaves CUs idle or
-        // with one latency-bound block each.  HUDIFF_X3_SMALL_GRID = largest 128 x 128 grid that takes them (300: B = 8 antibodies
+        // with one latency-bound block each.  HD_OPT_SMALL_GRID = largest 128 x 128 grid that takes them (300: B = 8 antibodies
         // 20.0 -> 25.1 sequences/s, B = 16 36.5 -> 42.4, B = 48 73.3 -> 78.4; larger limits lose again).
-        static const long small_grid = [] { const char* e = getenv("HUDIFF_X3_SMALL_GRID"); return e ? atol(e) : 300L; }();
+        const long small_grid = m->opt[HD_OPT_SMALL_GRID];
         if (shape == 128 && ((rows0 + 127) / 128 + (rows1 + 127) / 128) * (long)(q.N / 128) <= small_grid) shape = 64;
         // ... and 32 x 128 tiles (four waves side by side, 32 x 32 each) when even those leave most CUs empty (a handful of sequences)
-        static const long tiny_grid = [] { const char* e = getenv("HUDIFF_X3_TINY_GRID"); return e ? atol(e) : 150L; }();
+        const long tiny_grid = m->opt[HD_OPT_TINY_GRID];
         if (shape == 64 && ((rows0 + 63) / 64 + (rows1 + 63) / 64) * (long)(q.N / 128) <= tiny_grid) { shape = 32; pw = 32; }
         const int bm = shape <= 64 ? shape : (shape == 128 ? 128 : 256), bn = shape == 512 ? 256 : 128;
         q.tiles0 = (rows0 + bm - 1) / bm;
@@ -962,13 +992,13 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
             // few blocks per CU: the K loop is a chain of DMA round trips (~0.8 us per k tile, whatever the grid), so a third LDS stage --
             // two tiles in flight, 60 KB, still two blocks per CU -- pays: B = 1 3.88 -> 4.60 sequences/s, B = 8 29.8 -> 32.8, B = 16
             // 45.7 -> 46.8 (Nb: 8.47 -> 9.51, 64.7 -> 71.1, 120.6 -> 130.4).  Four stages (80 KB, one block per CU) gain less and lose
-            // from B = 16 on (instantiation removed).  HUDIFF_X3_TINY_NS = 2 restores two stages.
-            static const int ns = [] { const char* e = getenv("HUDIFF_X3_TINY_NS"); return e ? atoi(e) : 3; }();
+            // from B = 16 on (instantiation removed).  HD_OPT_TINY_STAGES = 2 restores two stages.
+            const int ns = (int)m->opt[HD_OPT_TINY_STAGES];
             // ... with four extra waves per block that only issue the operand DMA (gemm_x3_k, LW): the five DMA instructions per k tile and
             // the chain of six dependent MFMAs then run in different waves (B = 1 4.61 -> 4.92 sequences/s, B = 8 33.3 -> 34.4, Nb B = 8
             // 72.4 -> 77.0).  Such a block takes a CU alone (512 threads, 146 registers), so only while all lanes' blocks of the launch
-            // fit one per CU (B = 16 on two lanes: 52.3 -> 49.5 otherwise).  HUDIFF_X3_LOADERS=0 switches them off.
-            static const int loaders = [] { const char* e = getenv("HUDIFF_X3_LOADERS"); return e ? atoi(e) : 1; }();
+            // fit one per CU (B = 16 on two lanes: 52.3 -> 49.5 otherwise).  HD_OPT_LOADER_WAVES = 0 switches them off.
+            const int loaders = (int)m->opt[HD_OPT_LOADER_WAVES];
             if (loaders && ns == 3 && (long)q.tiles_m * q.tiles_n * (m->in_session ? m->nlanes : 1) <= 256) {
                 if (conv) hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, true, 3, 4>), grid, dim3(512), 0, st, q);
                 else hipLaunchKernelGGL((gemm_x3_k<32, 128, 1, 4, false, 3, 4>), grid, dim3(512), 0, st, q);
@@ -983,18 +1013,21 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         } else if (shape == 64) {
             // three stages (72 KB, still two blocks per CU) while the launch has at most one block per CU: B = 16 48.3 -> 51.4 sequences/s,
             // Nb B = 32 200.4 -> 205.9; with 257 .. 384 blocks it gains in places (Nb B = 64 301 -> 317) and loses in others (B = 48
-            // 82.2 -> 78.1), so larger grids keep two stages.  HUDIFF_X3_SMALL_NS = 2 / 3 forces, HUDIFF_X3_SMALL_NS3_MAX moves the limit.
-            static const int ns64 = [] { const char* e = getenv("HUDIFF_X3_SMALL_NS"); return e ? atoi(e) : 0; }();
-            static const long ns3_max = [] { const char* e = getenv("HUDIFF_X3_SMALL_NS3_MAX"); return e ? atol(e) : 256L; }();
+            // 82.2 -> 78.1), so larger grids keep two stages.  HD_OPT_SMALL_STAGES = 2 / 3 forces, HD_OPT_SMALL_STAGES3_MAX_GRID moves the limit.
+            const int ns64 = (int)m->opt[HD_OPT_SMALL_STAGES];
+            const long ns3_max = m->opt[HD_OPT_SMALL_STAGES3_MAX_GRID];
             if (ns64 == 3 || (ns64 == 0 && (long)q.tiles_m * q.tiles_n <= ns3_max)) {
                 if (conv) hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, true, 3>), grid, dim3(256), 0, st, q);
                 else hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, false, 3>), grid, dim3(256), 0, st, q);
             } else
             if (conv) hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
             else hipLaunchKernelGGL((gemm_x3_k<64, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);
+        } else if (q.ln_sync) {      // the 128 x 128 tile exists per epilogue set (gemm_x3_k, EPISET): the meeting epilogue has its own registers
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true, 2, 0, 2>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2, 0, 2>), grid, dim3(256), 0, st, q);
         } else {
-            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true, 2>), grid, dim3(256), 0, st, q);
-            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2>), grid, dim3(256), 0, st, q);
+            if (conv) hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, true, 2, 0, 1>), grid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL((gemm_x3_k<128, 128, 2, 2, false, 2, 0, 1>), grid, dim3(256), 0, st, q);
         }
     } else
     if (big && fast_ok && tiles128 < small_tiles) {
@@ -1002,7 +1035,6 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         launch_gemm_t<64, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else if (big) {
         if (gemm_bk() == 32 || !fast_ok) launch_gemm_t<128, 128, 2, 2, 32>(p, conv, per_seg, st);
-        else if (gemm_nbuf() == 2) launch_gemm_t<128, 128, 2, 2, 16, 2>(p, conv, per_seg, st);
         else launch_gemm_t<128, 128, 2, 2, 16>(p, conv, per_seg, st);
     } else {
         launch_gemm_t<32, 128, 1, 4, 32>(p, conv, per_seg, st);
@@ -1120,24 +1152,18 @@ static void bytenet_block(HdModel* m, const Segs& sg, const ByteNetW& w, int din
     const LnApply ap{w.ln2_g, w.ln2_b, dh, act};
     launch_gemm(m, p, false, true, STATS_NONE, &ap);
 
-    // HUDIFF_PFF3_APPLY=1 (A/B aid, VERDICT r2 "Next" #8): h2 <- act(LN(h2)) in place by ln_apply_k as well, so that the last
-    // projection runs without its LayerNorm + activation prologue (recomputed per N tile otherwise).  Measured again in round 3
-    // (DESIGN.md section 8): the extra HBM pass still costs more than the prologue -- off.
-    static const bool pff3_apply = [] { const char* e = getenv("HUDIFF_PFF3_APPLY"); return e && atoi(e) == 1; }();
+    // (normalising h2 in place by ln_apply_k as well, so that the last projection runs without its prologue, was measured in rounds 2
+    // and 3: the extra HBM pass costs more than the prologue recomputed per N tile -- NOTES.md)
     p = base_gemm(m, sg);
     p.A = h1; p.lda = dh; p.W = w.wc; p.bias = w.bc; p.C = h2; p.ldc = dh; p.N = dh; p.Kc = dh; p.taps = ks; p.dil = w.dil;
     p.w_stride = (long)ks * dh * dh; p.n_stride = dh; p.k_stride = dh;
-    const LnApply ap3f{w.ln3_g, w.ln3_b, dh, act};
-    if (pff3_apply) launch_gemm(m, p, true, true, STATS_NONE, &ap3f);
-    else launch_gemm(m, p, true, true, STATS_PARTIALS);
+    launch_gemm(m, p, true, true, STATS_PARTIALS);
 
     p = base_gemm(m, sg);
     p.A = h2; p.lda = dh; p.W = w.w3; p.bias = w.b3; p.C = out; p.ldc = ldo; p.N = din; p.Kc = dh;
     p.w_stride = (long)dh * din; p.n_stride = din; p.k_stride = dh;
-    if (!pff3_apply) {
-        p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
-        use_partials(m, p);
-    }
+    p.gamma = w.ln3_g; p.beta = w.ln3_b; p.pro_act = act;
+    use_partials(m, p);
     p.resid = x; p.ldr = ldx; p.extra = extra; p.lde = lde;
     p.C2 = out_split;
     set_drop(p, dr);
@@ -1169,6 +1195,34 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     GemmP p = base_gemm(m, sg);
     p.A = x; p.lda = D; p.W = w.wqkv; p.bias = w.bqkv; p.C = cur(m).ws.QKV; p.ldc = 3 * A; p.N = 3 * A; p.Kc = D;
     if (ln) { p.ln_fold = 1; use_partials(m, p); }      // LayerNorm folded into wqkv / bqkv (hd_finalize)
+    // The projection fused into the attention core (hd_attn_fused.hip.h: one workgroup per (sequence, head group) computes its heads' Q | K | V
+    // from the split input rows, leaves K / V in LDS and runs the attention on them): split route, the two shipped lengths, 64-wide heads.
+    // (two heads of the short model share a workgroup: their planes must leave the co-residency slack, i.e. L <= 156 -- a 160-slot model,
+    //  whose planes would fill the CU's 160 KB to the last byte, keeps the two-launch form)
+    const bool fuse19 = m->L > 16 * 18 && m->L <= 16 * 19,
+               fuse10 = m->L > 16 * 9 && m->L <= 16 * 10 && m->cfg.nhead % 2 == 0 && lds_fill_ok(QaGeom<10, 2>::smem(m->L), QA_THREADS);
+    const long fused_blocks = (long)sg.B * (m->cfg.nhead / (fuse19 ? 1 : 2)) * (m->in_session ? m->nlanes : 1);      // workgroups of all lanes' launches
+    if (x3 && x_split && w.wqkvx.w && m->opt[HD_OPT_FUSED_ATTN] && fused_blocks >= m->opt[HD_OPT_FUSED_ATTN_MIN_GRID] && m->opt[HD_OPT_SPLIT_ATTN] && (fuse19 || fuse10) && D % X3_BK == 0 && A % X3_BN == 0 &&
+        (long)sg.rows() * 3 * A * 4 < (1L << 31) && (long)sg.rows() * D * 4 < (1L << 31)) {
+        QkvAttnP q{};
+        q.X = x_split; q.ldx = D; q.x_bytes = (uint32_t)((long)sg.rows() * D * 4);
+        q.Wx = w.wqkvx.w; q.acc_scale = w.wqkvx.acc_scale; q.bias = w.bqkv;
+        q.ln_fold = p.ln_fold; q.stats = p.stats; q.spart = p.spart; q.spw = p.spw; q.spart_rows = p.spart_rows;
+        q.QKV = cur(m).ws.QKV; q.ldq = 3 * A; q.att = A; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.rope_cs = m->rope_cs;
+        q.O = cur(m).ws.O; q.ldo = A; q.nhead = m->cfg.nhead; q.sg = sg; q.rs = cur(m).rs;
+        static const int qa_abl = [] { const char* e = getenv("HUDIFF_QA_ABL"); return e ? atoi(e) : 0; }();      // (probes only)
+        q.abl = qa_abl;
+        const int NH = fuse19 ? 1 : 2;
+        dim3 fgrid((unsigned)(((sg.B + 7) / 8) * 8 * (m->cfg.nhead / NH)));
+        if (fuse19) hipLaunchKernelGGL((qkv_attn_x3_k<19, 1>), fgrid, dim3(QA_THREADS), lds_request(QaGeom<19, 1>::smem(m->L), QA_THREADS), st, q);
+        else hipLaunchKernelGGL((qkv_attn_x3_k<10, 2>), fgrid, dim3(QA_THREADS), lds_request(QaGeom<10, 2>::smem(m->L), QA_THREADS), st, q);
+        p = base_gemm(m, sg);
+        p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
+        p.resid = resid; p.ldr = D;
+        use_x3(p, w.wox); p.C2 = out_split;
+        launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
+        return;
+    }
     if (x3) { p.A = x_split; use_x3(p, w.wqkvx); }
     launch_gemm(m, p, false, false);
     // dynamic LDS requests obey the co-residency rule (hd_kernels.hip.h): a request whose co-resident blocks would fill the
@@ -1176,18 +1230,19 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     const size_t smem = lds_request((int)((size_t)m->L * (ATT_KS + att_vs(m->L > 160 ? 19 : 10)) * sizeof(float)), ATT_THREADS);
     dim3 grid(sg.B * m->cfg.nhead);
     // x3: the out-projection reads O in split form; L in (160, 304] has a split-precision attention kernel as well
-    static const bool ax_on = [] { const char* e = getenv("HUDIFF_X3_ATTN"); return !(e && atoi(e) == 0); }();
+    const bool ax_on = m->opt[HD_OPT_SPLIT_ATTN] != 0;
     // attn_x3_k<KT> masks only its last key tile: 16 (KT - 1) < L <= 16 KT (291 and 152 qualify); other lengths keep attn_k
     // ... and address QKV with 32-bit byte offsets
     // m->attn_x3 (default; HUDIFF_ATTN_X3=0 at hd_finalize turns it off): the split-precision attention kernel inside the fp32 path as
     // well (fp32 Q|K|V in, fp32 O out)
-    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= big_rows())) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
+    const bool ax_ok = ((x3 && ax_on) || (m->attn_x3 && !m->x3_suspended && sg.rows() >= m->opt[HD_OPT_BIG_MIN_ROWS])) && (long)sg.rows() * 3 * A * 4 < (1L << 31);
     const RunState* rsp = cur(m).rs;
     const int osp = x3 ? 1 : 0;
     // few sequences: two workgroups per (sequence, head), each with half of the query tiles (one round of the tile loop instead of two)
-    static const int ax_split_max = [] { const char* e = getenv("HUDIFF_ATTN_QSPLIT_MAX"); return e ? atoi(e) : 128; }();
-    if (ax_ok && (int)grid.x <= ax_split_max) grid.y = 2;
-    static const bool ax_w8 = [] { const char* e = getenv("HUDIFF_ATTN_WAVES"); return e && atoi(e) == 8; }();
+    // (only the attn_x3_k branches below read blockIdx.y: a length outside their windows falls through to attn_k with grid.y = 1)
+    const bool ax_kernel = ax_ok && ((m->L > 16 * 18 && m->L <= 16 * 19) || (m->L > 16 * 9 && m->L <= 16 * 10));
+    if (ax_kernel && (long)grid.x <= m->opt[HD_OPT_ATTN_QSPLIT_MAX_GRID]) grid.y = 2;
+    const bool ax_w8 = m->opt[HD_OPT_ATTN_WAVES] == 8;
     if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19 && !ax_w8)
         hipLaunchKernelGGL((attn_x3_k<19, AX19_THREADS>), grid, dim3(AX19_THREADS), lds_request(AxGeom<19>::SMEM, AX19_THREADS), st, cur(m).ws.QKV, 3 * A, A, m->rope_cos, m->rope_sin, cur(m).ws.O, A, m->cfg.nhead, sg, osp, rsp);
     else if (ax_ok && m->L > 16 * 18 && m->L <= 16 * 19)
@@ -1225,21 +1280,19 @@ static HdStatus static_branch(HdModel* m, const Segs& sg) {
     return HD_OK;
 }
 
-// Forms of the pruned tail (hd_tail_fused.hip.h).  HUDIFF_TAIL: 0 = the separate launches below, 1 = one kernel per step (one workgroup
-// per sequence, the draw included), 2 = five sliced launches + sample_step_k: the default for lanes of at most HUDIFF_TAIL_MAX_B (64)
-// sequences, where the tail is a visible part of a step; above, the separate launches are as fast or faster (Nb, 512 sequences: 465
-// against 455 sequences/s).
-enum { TAIL_LAUNCHES = 0, TAIL_ONE = 1, TAIL_SLICED = 2 };
+// Forms of the pruned tail (hd_tail_fused.hip.h).  HD_OPT_TAIL_FORM / HUDIFF_TAIL: 0 = the separate launches below, 2 = five sliced
+// launches + sample_step_k: the default for lanes of at most HD_OPT_TAIL_MAX_B (64) sequences, where the tail is a visible part of a
+// step; above, the separate launches are as fast or faster (Nb, 512 sequences: 465 against 455 sequences/s).  (1 was round 4's
+// one-workgroup-per-sequence kernel: not faster, moved to scripts/experiments/tail_fused_k.hip.h.)
+enum { TAIL_LAUNCHES = 0, TAIL_SLICED = 2 };
 static int tail_form(const HdModel* m, int B) {
-    static const int want = [] { const char* e = getenv("HUDIFF_TAIL"); return e ? atoi(e) : (int)TAIL_SLICED; }();
-    static const bool value_via_rows = [] { const char* e = getenv("HUDIFF_PRUNE_V"); return !(e && atoi(e) == 0); }();
+    const int want = (int)m->opt[HD_OPT_TAIL_FORM];
+    const bool value_via_rows = m->opt[HD_OPT_PRUNE_VALUE_VIA_ROWS] != 0;
     const int D = m->D, A = m->A, Fd = m->Fd;
     const bool one_ok = value_via_rows && m->cfg.nhead <= RV_MAX_HEADS && m->cfg.nhead * ATT_HD == A && m->L <= TAIL_MAXL && D <= TAIL_MAXD && D % 8 == 0 &&
-                        A <= TAIL_MAXA && A % 64 == 0 && Fd <= TAIL_MAXF && Fd % 2 == 0 && D / 4 <= TAIL_THREADS;
+                        A <= TAIL_MAXA && A % 64 == 0 && Fd <= TAIL_MAXF && Fd % 2 == 0 && D / 4 <= TC_THREADS;
     const bool sliced_ok = one_ok && (D == 768 || D == 512) && A == 512 && Fd == 256 && m->cfg.nhead == 8;      // the shipped widths
-    static const int max_b = [] { const char* e = getenv("HUDIFF_TAIL_MAX_B"); return e ? atoi(e) : 64; }();
-    if (want == TAIL_SLICED) return sliced_ok && B <= max_b ? TAIL_SLICED : TAIL_LAUNCHES;
-    if (want == TAIL_ONE) return one_ok ? TAIL_ONE : TAIL_LAUNCHES;
+    if (want == TAIL_SLICED) return sliced_ok && B <= m->opt[HD_OPT_TAIL_MAX_ROWS] ? TAIL_SLICED : TAIL_LAUNCHES;
     return TAIL_LAUNCHES;
 }
 template <int D>
@@ -1261,8 +1314,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     cs.nseg = 1; cs.B = B; cs.L = 1; cs.len[0] = 1;
     // K projection of LN1(at) for every row (columns [A, 2A) of the fused weight).  V is never projected for all rows:
     // the one query of each sequence takes its value side through the input rows (row_value_k / head_proj_k).
-    static const bool value_via_rows = [] { const char* e = getenv("HUDIFF_PRUNE_V"); return !(e && atoi(e) == 0); }();
-    const bool via_rows = value_via_rows && m->cfg.nhead <= RV_MAX_HEADS && m->L <= 320;
+    const bool via_rows = m->opt[HD_OPT_PRUNE_VALUE_VIA_ROWS] != 0 && m->cfg.nhead <= RV_MAX_HEADS && m->L <= 320;
     GemmP p = base_gemm(m, sg);
     p.A = ws.AT; p.lda = D; p.W = w.a2.wqkv + A; p.ldw = 3 * A; p.bias = w.a2.bqkv + A; p.C = ws.QKV + A; p.ldc = 3 * A;
     p.N = via_rows ? A : 2 * A; p.Kc = D; p.ln_fold = 1;
@@ -1270,7 +1322,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     const float2* at_part = p.spart; const int at_pw = p.spw; const long at_rows = p.spart_rows;
     if (att_x3(m, sg)) { p.A = ws.ATX; use_x3(p, w.a2.wqkvx, A / X3_BN); }     // column slice [A, ...) = n tiles from A / 128 on
     launch_gemm(m, p, false, false);
-    if (const int form = tail_form(m, B)) {        // everything behind the K projection in one or five launches (hd_tail_fused.hip.h)
+    if (tail_form(m, B) == TAIL_SLICED) {          // everything behind the K projection in five launches (hd_tail_fused.hip.h)
         TailP t{};
         t.AT = ws.AT; t.Y = ws.Y; t.D = D; t.QKV = ws.QKV; t.ldq = 3 * A; t.A = A;
         t.at_part = at_part; t.at_pw = at_pw; t.at_rows = at_rows;
@@ -1280,8 +1332,7 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
         t.Xc = ws.Xc; t.nhead = m->cfg.nhead; t.sg = sg;
         t.head = m->head; t.tokens = ws.tokens; t.q_noise = m->s_has_q ? m->qnoise : nullptr; t.q_rows = m->sB; t.q_off = cur(m).row_off;
         t.PW = ws.PW; t.OP = ws.YV; t.ATc = ws.ATc; t.F1c = ws.F1c;
-        if (form == TAIL_ONE) hipLaunchKernelGGL(tail_fused_k, dim3(B), dim3(TAIL_THREADS), 0, st, t);
-        else if (D == 768) launch_tail_sliced<768>(t, B, m->cfg.nhead, Fd, st);
+        if (D == 768) launch_tail_sliced<768>(t, B, m->cfg.nhead, Fd, st);
         else launch_tail_sliced<512>(t, B, m->cfg.nhead, Fd, st);
         return;
     }
@@ -1325,42 +1376,8 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     const HdConfig& c = m->cfg;
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
     const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
-    // The token-encoder stack as ONE kernel (hd_enc_fused.hip.h): split route, the shipped widths (256 / 128, kernel 7), chains of at
-    // most 160 slots.  OFF by default (HUDIFF_ENC_FUSED=1 turns it on): correct to 1e-6 of the per-GEMM launches, but measured slower --
-    // 597 us per (sequence, chain) workgroup against 290 us for the 36 launches at B = 1, 731 against ~735 us per 128-sequence lane:
-    // with one wave per SIMD (x register-resident) the LayerNorm / GELU / split passes cannot overlap the MFMAs.
-    static const bool enc_fused_on = [] { const char* e = getenv("HUDIFF_ENC_FUSED"); return e && atoi(e) == 1; }();
-    bool enc_fused = enc_fused_on && m->x3 && !m->x3_suspended && d == 256 && dh == 128 && c.kernel_size == 7 &&
-                     c.n_encoder_layers >= 1 && c.n_encoder_layers <= ENC_MAX_LAYERS && sg.len[0] <= ENC_ROWS && (sg.nseg == 1 || sg.len[1] <= ENC_ROWS);
-    for (int n = 0; enc_fused && n < c.n_encoder_layers; ++n) enc_fused = m->enc[n].w1x.w && m->enc[n].wcx.w && m->enc[n].w3x.w;
-    if (enc_fused) {
-        EncStackP ep{};
-        for (int sgi = 0; sgi < sg.nseg; ++sgi)
-            for (int n = 0; n < c.n_encoder_layers; ++n) {
-                const ByteNetW& w = m->enc[n];
-                EncLayerW& l = ep.lw[sgi][n];
-                l.w1 = w.w1x.w + (long)sgi * w.w1x.seg_stride; l.wc = w.wcx.w + (long)sgi * w.wcx.seg_stride; l.w3 = w.w3x.w + (long)sgi * w.w3x.seg_stride;
-                l.s1 = w.w1x.acc_scale; l.sc = w.wcx.acc_scale; l.s3 = w.w3x.acc_scale; l.dil = w.dil;
-                l.b1 = w.b1 + sgi * dh; l.bc = w.bc + sgi * dh; l.b3 = w.b3 + sgi * d;
-                l.g1 = w.ln1_g + sgi * d; l.e1 = w.ln1_b + sgi * d; l.g2 = w.ln2_g + sgi * dh; l.e2 = w.ln2_b + sgi * dh;
-                l.g3 = w.ln3_g + sgi * dh; l.e3 = w.ln3_b + sgi * dh;
-            }
-        ep.nlayers = c.n_encoder_layers; ep.act = c.enc_act;
-        ep.tokens = ws.tokens; ep.emb = m->emb; ep.extra = ws.EXTRA; ep.lde = d; ep.out = ws.FEAT; ep.ldo = D; ep.sg = sg; ep.rs = cur(m).rs;
-        static const int enc_abl = [] { const char* e = getenv("HUDIFF_ENC_ABL"); return e ? atoi(e) : 0; }();
-        ep.abl = enc_abl;
-        ep.drop_mode = (drop_mode != DROP_NONE && m->p_enc > 0.f) ? drop_mode : DROP_NONE;
-        if (ep.drop_mode != DROP_NONE) {
-            GemmP tmp{}; Drop dr; dr.mode = drop_mode; dr.p = m->p_enc;
-            set_drop(tmp, dr);
-            ep.drop_thresh = tmp.drop_thresh; ep.drop_scale = tmp.drop_scale;
-            ep.drop_mask = enc_masks; ep.mask_layer_stride = (long)enc_stride;
-        }
-        if (c.enc_act == HD_ACT_GELU) hipLaunchKernelGGL(enc_stack_x3_k<ACT_GELU>, dim3(sg.B, sg.nseg), dim3(256), 0, st, ep);
-        else hipLaunchKernelGGL(enc_stack_x3_k<ACT_RELU>, dim3(sg.B, sg.nseg), dim3(256), 0, st, ep);
-    } else
     hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
-    for (int n = 0; !enc_fused && n < c.n_encoder_layers; ++n) {
+    for (int n = 0; n < c.n_encoder_layers; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
@@ -1387,6 +1404,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         const AttBlockW& w = m->att[n];
         // at = x + A1(x)
         attention_layer(m, sg, w.a1, ws.Y, false, ws.Y, ws.AT, /*want_out_stats=*/true, ax3, ws.YX, ws.ATX);
+        if (m->debug_stop_after == 100 + n) return HD_OK;        // (tests: right behind the first attention of block n)
         // at = at + A2(LN1(at))      (statistics of `at` come from the out-projection's epilogue)
         if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
         attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true, ax3, ws.ATX, ws.ATX);
@@ -1451,7 +1469,7 @@ static int drop_mode_of(const HdModel* m, uint32_t flags) {
 // split-precision kernels (whole path or attention only) currently in use / switched off for good by the range guard
 static bool split_active(const HdModel* m) { return (m->x3 || m->attn_x3) && !m->x3_suspended; }
 // which kernels a captured step graph holds: split kernels in use, ln_sync level
-static int kernel_set(const HdModel* m) { return (split_active(m) ? 1 : 0) | (m->lnsync_level << 1) | (m->nlanes << 4); }       // (the lane count picks kernels too: launch_gemm)
+static int kernel_set(const HdModel* m) { return (split_active(m) ? 1 : 0) | ((m->lnsync_level & 3) << 1) | (m->nlanes << 4); }       // (the lane count picks kernels too: launch_gemm)
 static void suspend_split(HdModel* m) {
     // said once per handle (stderr; HUDIFF_QUIET=1 silences it): from here on the handle runs the all-fp32 kernels, at their speed
     static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();
@@ -1463,12 +1481,11 @@ static void suspend_split(HdModel* m) {
     for (auto& ln : m->lane) ln.drop_graphs();      // captured with the split kernels
 }
 
-static void suspend_lnsync(HdModel* m, uint32_t bits) {
+static void suspend_lnsync(HdModel* m) {
     static const bool quiet = [] { const char* e = getenv("HUDIFF_QUIET"); return e && atoi(e) == 1; }();
     if (!quiet)
-        fprintf(stderr, "[hudiff_hip] an ln_sync meeting failed (%s): this call is repeated with separate LayerNorm passes and the handle keeps "
-                        "them (hd_precision_report.lnsync_fallbacks)\n",
-                (bits & 1) ? "timed out: the blocks of an M tile did not run together" : "the blocks of an M tile ran on different XCDs");
+        fprintf(stderr, "[hudiff_hip] an ln_sync meeting timed out (the blocks of an M tile did not run together): this call is repeated with "
+                        "separate LayerNorm passes and the handle keeps them (hd_precision_report.lnsync_fallbacks)\n");
     m->lnsync_level = 0;
     m->lnsync_fallbacks += 1;
     m->debug_lnsync_fail = false;
@@ -1490,7 +1507,7 @@ static HdStatus check_guards(HdModel* m, int nlanes, bool* numeric) {
     if (numeric) *numeric = pad[0] != 0;
     if (pad[3]) m->lnsync_cross_xcd = true;         // an ln_sync meeting spanned two XCDs: correct (write-through hand-over), slower
     if (m->s_dirty) return HD_OK;                   // already known; nothing more is read out of an invalid run
-    if (pad[2] && m->x3 && !m->x3_suspended && m->lnsync_level > 0) { suspend_lnsync(m, pad[2]); m->s_dirty = true; }
+    if (pad[2] && m->x3 && !m->x3_suspended && m->lnsync_level > 0) { suspend_lnsync(m); m->s_dirty = true; }
     else if (pad[1] && split_active(m)) { suspend_split(m); m->s_dirty = true; }
     return HD_OK;
 }
@@ -1557,11 +1574,9 @@ static HdStatus one_step(HdModel* m, const Segs& sg, int dm, const uint8_t* em, 
     HD_TRY(forward_body(m, sg, dm, em, cm, prune));
     Workspace& ws = ln.ws;
     // the injected Exp(1) noise lives once, for the whole batch, in the model (m->qnoise)
-    if (!(prune && tail_form(m, sg.B) == TAIL_ONE))   // (the one-kernel tail draws the token itself); its last workgroup advances the step
-        hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64 * SS_WAVES), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
-                           ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0, 1);
-    else
-        hipLaunchKernelGGL(advance_step_k, dim3(1), dim3(1), 0, ln.stream, ln.rs);
+    // (the last workgroup of sample_step_k advances the step)
+    hipLaunchKernelGGL(sample_step_k, dim3(sg.B), dim3(64 * SS_WAVES), 0, ln.stream, prune ? ws.Xc : ws.Y, m->D, m->head, ws.tokens, ws.order,
+                       ws.T, m->sTmax, m->s_has_q ? m->qnoise : nullptr, m->sB, ln.row_off, ln.rs, sg, prune ? 1 : 0, 1);
     HIP_TRY(hipGetLastError());
     return HD_OK;
 }
@@ -1591,8 +1606,8 @@ static HdStatus sample_begin_impl(HdModel* m, const int32_t* tokens, const int32
     if (dm == DROP_INJECT && (!enc_masks || !conv_masks)) return fail(HD_ERR_INVALID, "hd_sample_begin: HD_DROPOUT_INJECT needs masks");
     // two concurrent half-batches unless the batch is small, masks are injected (their layout is per full batch)
     // or the caller asked for one lane
-    static const int lane_min_b = [] { const char* e = getenv("HUDIFF_LANE_MIN_B"); int v = e ? atoi(e) : 16; return v < 2 ? 2 : v; }();      // two lanes pay from 16 rows on since the small-launch latency work (B = 16: 50.8 -> 52.9 sequences/s, B = 24: 57.7 -> 62.1, B = 32: 69.9 -> 72.4; B = 8 loses: 33.1 -> 30.6); 40 before it
-    m->nlanes = (B >= lane_min_b && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? lanes_default() : 1;
+    const long lane_min_b = m->opt[HD_OPT_LANE_MIN_ROWS];
+    m->nlanes = (B >= lane_min_b && dm != DROP_INJECT && !(flags & HD_ONE_LANE)) ? (int)m->opt[HD_OPT_LANES] : 1;
     if (m->nlanes > B) m->nlanes = B;
     for (int l = 0, off = 0; l < m->nlanes; ++l) {            // balanced contiguous row blocks
         const int Bl = B / m->nlanes + (l < B % m->nlanes ? 1 : 0);
@@ -1726,8 +1741,7 @@ extern "C" HdStatus hd_sample_run(HdModel* m, int32_t t0, int32_t t1) {
     // nodes of the captured step (the step counter lives on the device, so every step is the same node) -- kept for the next
     // sample with the same number of steps.  Default: the step graph is launched t1 - t0 times, which measured 2.4 % faster
     // (the lanes interleave more freely between step graphs than inside two 20 000-node graphs).
-    static const int loop_env = [] { const char* e = getenv("HUDIFF_LOOP_GRAPH"); return e ? atoi(e) : 0; }();
-    const bool loop_graph = loop_env || (m->sflags & HD_LOOP_GRAPH);
+    const bool loop_graph = m->opt[HD_OPT_LOOP_GRAPH] != 0 || (m->sflags & HD_LOOP_GRAPH);
     if (use_graph && loop_graph && t1 - t0 > 1) {
         for (int l = 0; l < m->nlanes; ++l) {
             HdModel::Lane& ln = m->lane[l];
@@ -1867,6 +1881,31 @@ extern "C" HdStatus hd_precision_info(HdModel* m, int32_t* split_built, int32_t*
     return HD_OK;
 }
 
+extern "C" HdStatus hd_set_option(HdModel* m, int32_t option, int64_t value) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_set_option: null model");
+    if (option < 0 || option >= HD_OPT_COUNT) return fail(HD_ERR_INVALID, "hd_set_option: unknown option %d", option);
+    const OptDef& d = OPTS[option];
+    if (!opt_legal(d, value)) return fail(HD_ERR_INVALID, "hd_set_option: value %lld is not legal for option %d (%s)", (long long)value, option, d.env);
+    if (m->in_session) return fail(HD_ERR_STATE, "hd_set_option: a sampling session is open");
+    if (d.create_only && m->finalized) return fail(HD_ERR_STATE, "hd_set_option: option %d (%s) is fixed at hd_finalize", option, d.env);
+    if (m->opt[option] == value) return HD_OK;
+    m->opt[option] = value;
+    if (option == HD_OPT_LNSYNC_LEVEL && m->lnsync_level == m->lnsync_level_cfg) m->lnsync_level = (int)value;      // (a handle whose guard fired keeps level 0 until hd_precision_reset)
+    if (option == HD_OPT_LNSYNC_LEVEL) m->lnsync_level_cfg = (int)value;
+    if (m->finalized) {
+        hipSetDevice(m->device);
+        for (auto& ln : m->lane) { if (ln.stream) hipStreamSynchronize(ln.stream); ln.drop_graphs(); }      // captured with the old choice
+    }
+    return HD_OK;
+}
+
+extern "C" HdStatus hd_get_option(HdModel* m, int32_t option, int64_t* value) {
+    if (!m || !value) return fail(HD_ERR_INVALID, "hd_get_option: null argument");
+    if (option < 0 || option >= HD_OPT_COUNT) return fail(HD_ERR_INVALID, "hd_get_option: unknown option %d", option);
+    *value = m->opt[option];
+    return HD_OK;
+}
+
 extern "C" HdStatus hd_sample(HdModel* m, int32_t* tokens, const int32_t* region, const int32_t* chain,
                               const int32_t* order, const int32_t* T, int32_t B, int32_t Tmax, uint32_t flags,
                               uint64_t seed, uint64_t row0, const float* q_noise,
@@ -1909,6 +1948,14 @@ extern "C" HdStatus hd_debug_fail_next_lnsync(HdModel* m) {
     return HD_OK;
 }
 
+extern "C" HdStatus hd_debug_scatter_lnsync(HdModel* m, int32_t on) {
+    if (!m) return fail(HD_ERR_INVALID, "hd_debug_scatter_lnsync: null model");
+    if (m->in_session) return fail(HD_ERR_STATE, "hd_debug_scatter_lnsync: a sampling session is open");
+    m->debug_lnsync_scatter = on != 0;
+    for (auto& ln : m->lane) ln.drop_graphs();
+    return HD_OK;
+}
+
 extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats) {
     if (!m || !name || !out) return fail(HD_ERR_INVALID, "hd_debug_read: null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -1922,6 +1969,8 @@ extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float
     else if (k == "POS") { src = ws.POS; width = m->d; }
     else if (k == "EXTRA") { src = ws.EXTRA; width = m->d; }
     else if (k == "AT") { src = ws.AT; width = m->D; }
+    else if (k == "O") { src = ws.O; width = m->A; }              // (split route: X16 rows -- per 32 columns 32 fp16 high parts, then 32 low parts)
+    else if (k == "QKV") { src = ws.QKV; width = 3 * m->A; }
     else return fail(HD_ERR_INVALID, "hd_debug_read: unknown buffer %s", name);
     if (B > ws.capB || n_floats != (int64_t)B * m->L * width) return fail(HD_ERR_INVALID, "hd_debug_read: size mismatch");
     // rows are segment-major on the device; return them as [B, L, width]

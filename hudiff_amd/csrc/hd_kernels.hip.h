@@ -31,6 +31,10 @@
 #include <stdint.h>
 #include <type_traits>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "hd_kernels.hip.h is written for gfx950 (CDNA4) only: wave64, MFMA 32x32x16 f16, buffer_load ... lds, 160 KB LDS, s_barrier semantics of ended waves"
+#endif
+
 namespace hd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -181,8 +185,8 @@ struct GemmP {
     // split-precision variant (gemm_x3_k): W as pre-tiled (hi, lo) fp16 planes scaled by a power of two, per segment at
     // + seg * wx_stride halfs; acc_scale = 2^-(weight shift + activation shift) undoes the scaling in the epilogue
     const uint16_t* Wx; long wx_stride; float acc_scale;
-    // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as, per group of 32 columns, 32 fp16
-    // high parts followed by 32 fp16 low parts (x ~= hi + lo; x16_hi()).  A (row, k tile of 32) is then ONE 128-byte cache line:
+    // Split activation format ("X16"): a row of K fp32 values is stored in the same 4 K bytes as, per group of 16 columns, 16 fp16
+    // high parts followed by 16 fp16 low parts (x ~= hi + lo; x16_hi(); groups of 32 until round 5).  A (row, k tile of 32) is ONE 128-byte cache line:
     // rounds 2-3 kept all K high parts, then all K low parts, so that every DMA request of a k tile touched two half lines per row
     // and the vector L1 -- far smaller than the A panels in flight -- fetched each line twice.  gemm_x3_k reads its A operand in this
     // form (written by its producer: ln_apply_k, attn_k / attn_x3_k, or a GEMM epilogue with c_split / C2 / ln_sync), so its K loop
@@ -227,7 +231,7 @@ struct GemmP {
     // per M tile: arrivals, departures, XCC ids seen, spare; self-resetting), merge the partials and write   S = act(LN(row; gamma2, beta2))   in
     // split form from the values they still hold in registers -- instead of a separate ln_apply_k pass that reads the fp32
     // rows back from HBM and writes S.  C may be null (S is the only output).  A wait that exceeds its budget raises
-    // RunState::pad[2] (the forward then fails with HD_ERR_STATE) -- never a hang.
+    // RunState::pad[2] (the host repeats the call with ln_apply_k passes and the handle keeps those, hd_api.hip check_guards) -- never a hang.
     int ln_sync; int* sync_ctr; float* S; const float* gamma2; const float* beta2; int act2; int k2_stride;
     // geometry
     Segs sg;
@@ -281,11 +285,16 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 #ifndef HD_SPLIT4_MODE
 #define HD_SPLIT4_MODE 0
 #endif
+#ifndef HD_X3_PRE
+#define HD_X3_PRE 1          // A/B aid: 0 builds gemm_x3_k without the residual prefetch ahead of the K loop
+#endif
 typedef _Float16 hd_f16x4 __attribute__((ext_vector_type(4)));
-// X16 row format (GemmP): half index of the HIGH part of column c; its low part sits 32 halfs further.  Columns c .. c + 3 of a
-// float4 (c % 4 == 0) stay contiguous.
-__host__ __device__ __forceinline__ constexpr int x16_hi(int c) { return ((c >> 5) << 6) | (c & 31); }
-constexpr int X16_LO = 32;
+// X16 row format (GemmP): half index of the HIGH part of column c; its low part sits X16_LO halfs further.  Columns c .. c + 3 of a
+// float4 (c % 4 == 0) stay contiguous.  Round 5: groups of SIXTEEN columns -- 16 fp16 high parts, then 16 low parts = 64 bytes -- so that
+// a k step of 16 columns of a row is one contiguous half cache line (rounds 2-4: groups of 32, hi and lo of a k step 64 bytes apart) and
+// a k tile of 32 columns is still one 128-byte line: qkv_attn_x3_k stages k steps, gemm_x3_k whole k tiles.
+__host__ __device__ __forceinline__ constexpr int x16_hi(int c) { return ((c >> 4) << 5) | (c & 15); }
+constexpr int X16_LO = 16;
 __device__ __forceinline__ void split4(const f32x4 v, hd_f16x4& hh, hd_f16x4& ll) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     hh = __builtin_convertvector(v, hd_f16x4);
@@ -323,10 +332,14 @@ __host__ __device__ __forceinline__ int epi_needs(const GemmP& p) {
            (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0) |
            (p.ln_sync ? EPI_LNSYNC : 0);
 }
-template <int BM, int BN, int WM, int WN, int F = EPI_ALL>
+// rows of a wave's 32-row pass that one wave instruction covers in the epilogue's float4 layout (WTN / 4 lanes per row)
+__host__ __device__ constexpr int epi_rpi(int wtn) { return 64 / (wtn / 4); }
+// PRE: the residual values of the block's output tile were requested BEFORE the K loop (gemm_x3_k: `pre`, one float4 per (pass, row
+// group) in this function's own lane layout) -- their HBM round trips travel under the K loop instead of opening every 32-row pass.
+template <int BM, int BN, int WM, int WN, int F = EPI_ALL, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
-                                              int by) {
+                                              int by, const f32x4 (&pre)[PRE ? BM / WM / 32 : 1][PRE ? 32 / epi_rpi(BN / WN) : 1]) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
@@ -409,7 +422,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
         // while the accumulators are transposed through LDS instead of serialising load -> store per row
         f32x4 rres[32 / RPI];
-        if (has_resid) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) rres[it] = pre[i][it];
+        } else if (has_resid) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int g0 = wrow0 + 32 * i + it * RPI;                       // uniform
@@ -995,7 +1011,8 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
 
     // EPI: the epilogue features this instantiation carries (chosen by the host, launch_gemm_t: one epilogue per kernel -- four
     // copies behind an in-kernel branch, as gemm_x3_k has them, push this 128-VGPR kernel into scratch: 600 spilled registers)
-    gemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
+    const f32x4 no_pre[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
+    gemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by, no_pre);
 }
 
 
@@ -1051,7 +1068,10 @@ __device__ __forceinline__ void lds_barrier() {
 // LW > 0: LW extra waves per block that only issue the operand DMA (waves NW .. NW + LW - 1), while the NW MFMA waves issue none: in the
 // small launches a wave's five DMA instructions per k tile (~0.2 us of issue) and its chain of six dependent MFMAs (~0.1 us) are otherwise
 // serial in the same wave.  LW must equal NW (the piece -> wave mapping is the MFMA waves' own).
-template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2, int LW = 0>
+// EPISET: which epilogues the instantiation carries -- 0 all of them (the launch picks by its features), 1 every one but the ln_sync
+// meeting, 2 the ln_sync ones only.  The 128 x 128 tile exists as 1 and 2 (launch_gemm picks by GemmP::ln_sync): the meeting epilogue
+// keeps a whole output tile in registers and would otherwise set the register count of every 128 x 128 launch.
+template <int BM, int BN, int WM, int WN, bool CONV, int NS = 2, int LW = 0, int EPISET = 0>
 __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 && LW == 0) ? 2 : 1) gemm_x3_k(const GemmP p) {
     static_assert(LW == 0 || LW == WM * WN, "loader waves mirror the MFMA waves");
     constexpr int BK = X3_BK, NW = WM * WN, NT = 64 * (NW + LW);
@@ -1081,6 +1101,9 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
         by = slot % p.tiles_n;
         bx = (slot / p.tiles_n) * 8 + xcd;
+        // test aid (hd_debug_scatter_lnsync, probe bit 8): consecutive workgroups -- which go to DIFFERENT XCDs -- are the N tiles of an
+        // M tile, so that the ln_sync meeting runs its cross-XCD path (same results, tests/test_gpu_x3.py)
+        if (p.x3_abl & 256) { by = b % p.tiles_n; bx = b / p.tiles_n; }
         if (bx >= p.tiles_m) return;
     }
     if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
@@ -1164,12 +1187,50 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Residual prefetch (PRE; the 128 x 128 instantiation: two blocks per CU leave 256 registers per wave).  The N = 768 projections
+    // (out-projection, PFF3, FF2) are bound by HBM round trips, not bytes: their epilogue used to open each 32-row pass with the
+    // residual loads of that pass (two exposed HBM latencies per wave, and no HBM reads at all while the K loop runs on L2-resident
+    // operands).  Every lane now asks for all the residual float4s it will add -- exactly the elements it overwrites, so an aliased
+    // output (C == resid) is safe -- before the first DMA; they are older than every DMA on the in-order vmcnt, so the first k tile's
+    // wait covers them (once per block), and they arrive while the other co-resident block computes.
+    constexpr bool PRE = HD_X3_PRE && BM == 128 && BN == 128 && NW == 4 && LW == 0;
+    constexpr int PRE_TM = PRE ? TM : 1, PRE_IT = PRE ? 32 / epi_rpi(WTN) : 1;
+    f32x4 pre[PRE_TM][PRE_IT];
+    if constexpr (PRE) {
+        constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+        const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
+        const int col = n0 + wn * WTN + e_c4;
+        const bool col_ok = col < p.N;
+        const uint32_t r_vo = (uint32_t)((e_r * p.ldr + (col_ok ? col : 0)) * 4);
+        const int wrow0 = m0 + wm * WTM;
+        if (p.resid != nullptr) {                                               // (uniform)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int g0 = wrow0 + 32 * i + it * RPI;                   // uniform
+                    const bool ok = g0 + e_r < seg_rows && col_ok;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(p.resid) + (long)(rbase + g0) * p.ldr, 0, 0x7FFFFFFF, 0x00020000);
+                    pre[i][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : BUF_OOB), 0, 0));
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) pre[i][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        pre[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
     // W fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
-    // chunk ^ ((r >> 2) & 3) of its 64-byte plane row; A fragment: high-part chunk 2 ks + g (low part: + 4) at slot
-    // chunk ^ ((r >> 1) & 7) of the 128-byte row.  The wave part and 32 t do not touch bits 1..3 of r.
+    // chunk ^ ((r >> 2) & 3) of its 64-byte plane row; A fragment (X16 groups of 16 columns: hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15 per
+    // k step): high-part chunk 4 ks + g (low part: + 2) at slot chunk ^ ((r >> 1) & 7) of the 128-byte row.  The wave part and 32 t do
+    // not touch bits 1..3 of r.
     const int fsw = (lane >> 2) & 3, fg = lane >> 5, asw = (lane >> 1) & 7;
     const int foff0 = (lane & 31) * 64 + (((0 + fg) ^ fsw) << 4), foff1 = (lane & 31) * 64 + (((2 + fg) ^ fsw) << 4);
-    const int aoff0 = (lane & 31) * 128 + (((0 + fg) ^ asw) << 4), aoff1 = (lane & 31) * 128 + (((2 + fg) ^ asw) << 4);
+    const int aoff0 = (lane & 31) * 128 + (((0 + fg) ^ asw) << 4), aoff1 = (lane & 31) * 128 + (((4 + fg) ^ asw) << 4);
     auto mma = [&](int st) {
         const char* At = St + st * STAGE_BYTES + wm * WTM * 128;
         const char* Wt = St + st * STAGE_BYTES + A_BYTES + wn * WTN * 64;
@@ -1187,7 +1248,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(At + oa + 32 * 128 * i);
-                al[i] = *reinterpret_cast<const f16x8*>(At + (oa ^ 64) + 32 * 128 * i);      // low parts: chunk + 4
+                al[i] = *reinterpret_cast<const f16x8*>(At + (oa ^ 32) + 32 * 128 * i);      // low parts: chunk + 2
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -1233,7 +1294,11 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         st_in = st;
         st = st + 1 == NS ? 0 : st + 1;
     }
-    if (LW > 0 && loader) return;                      // (the epilogue's barriers count the waves that are left)
+    // The loader waves end here, ahead of the epilogue's barriers (ln_sync meeting).  gfx9-family hardware (gfx950 included: ISA
+    // "s_barrier": a wave that has terminated no longer takes part) completes a barrier when every wave of the workgroup that has
+    // NOT ended arrived, so the four MFMA waves synchronise among themselves; the static_assert at the top of this file pins the
+    // target this relies on.
+    if (LW > 0 && loader) return;
     if (p.x3_abl & 8) {                                // probe: no epilogue (the accumulators stay live through a never-true store)
         float s = 0.f;
 #pragma unroll
@@ -1248,19 +1313,21 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
     const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
     const int need = p.x3_abl & 64 ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);
-#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
+#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3, PRE>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by, pre)
     if (need & EPI_LNSYNC) {
         // (only the 4-wave 128 x 128 instantiation is ever launched with ln_sync; the others keep the code out)
-        if constexpr (NW == 4) {
+        if constexpr (NW == 4 && EPISET != 1) {
             if (!(need & ~(EPI_PART | EPI_LNSYNC))) HD_EPI(EPI_PART | EPI_LNSYNC);
             else HD_EPI(EPI_ALL | EPI_LNSYNC);
         }
     }
-    else if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
-    else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
-    else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
-    else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
-    else HD_EPI(EPI_ALL);
+    else if constexpr (EPISET != 2) {
+        if (!(need & ~EPI_PART)) HD_EPI(EPI_PART);
+        else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
+        else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
+        else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
+        else HD_EPI(EPI_ALL);
+    }
 #undef HD_EPI
 }
 
@@ -1715,7 +1782,7 @@ __global__ void __launch_bounds__(ATT_THREADS, NKT <= 10 ? 4 : 2) attn_k(const f
                     _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
                     // x16_hi(64 h + 16 dt + 4 g) with dt a compile-time constant: lane part 128 h + 4 g, the rest an immediate (the
                     // generic shift-and-mask form cost the 128-VGPR kernels six to eight spilled registers)
-                    const int oc = 128 * h + 4 * g + 64 * (dt >> 1) + 16 * (dt & 1);
+                    const int oc = 128 * h + 4 * g + 32 * dt;
                     *reinterpret_cast<f16x4*>(orow + oc) = hh;
                     *reinterpret_cast<f16x4*>(orow + oc + X16_LO) = ll;
                 } else {
@@ -1757,123 +1824,20 @@ template <int KT> struct AxGeom {
 constexpr int AX_KROWS = AxGeom<19>::KROWS;        // longest sequence the kernel family covers
 constexpr int AX19_THREADS = 768;                  // block size of attn_x3_k<19> (HUDIFF_ATTN_WAVES=8 launches the 512-thread instantiation)
 
-// NTH: threads per block.  KT = 19 runs twelve waves (three per SIMD, 160 VGPRs): the tile loop's MFMA, LDS and vector-ALU phases of
-// three waves interleave better than those of two (227.9 -> 217.7 us per launch); KT = 10 keeps eight (two blocks per CU).
-template <int KT, int NTH = ATT_THREADS>
-__global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
-                                                            const float* __restrict__ rope_cos,
-                                                            const float* __restrict__ rope_sin,
-                                                            float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split,
-                                                            const RunState* __restrict__ rs) {
+// The query-tile loop of the split-precision attention core: K (rotated) and V^T planes are in LDS (Kh / Kl / Vh / Vl, the layouts
+// above); every wave walks over 16-query tiles -- Q from global (fp32 rows, rotated, pre-scaled and split here), S^T = K Q^T, softmax,
+// O^T = V^T P^T, O rows out.  Shared by attn_x3_k (K / V staged from the projection's fp32 rows) and qkv_attn_x3_k
+// (hd_attn_fused.hip.h: K / V written straight from the projection's accumulators).  QL2: the Q rows were stored by other waves
+// of THIS workgroup a moment ago (qkv_attn_x3_k): they are read past the L1 (sc0), where a line of the previous launch could linger.
+template <int KT, int NTH, bool QL2>
+__device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, const char* Vh, const char* Vl, const float* __restrict__ QKV, int ldq,
+                                              int qoff, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                              const __amdgpu_buffer_rsrc_t o_rs, int ldo, int b, int h, const Segs& sg, int o_split,
+                                              const RunState* __restrict__ rs, int lane, int wave) {
     typedef AxGeom<KT> G;
-    constexpr int AX_KT = KT, AX_KROWS = G::KROWS, AX_VKEYS = G::VKEYS, AX_KPLANE = G::KPLANE, AX_VPLANE = G::VPLANE;
-    // KT <= 10 (EXACT): the K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the
-    // nanobody model that is 79 872 B -- two blocks per CU with 4 KB to spare.  (With 160 zero-padded rows the block took 81 920 B,
-    // two blocks filled the CU's 163 840 B exactly, and blocks that started beside a running one produced wrong rows now and then.)
-    // Reads of keys >= L are then redirected to row L - 1 (their scores are masked anyway).  KT = 19 runs one block per CU: its
-    // planes keep 16 KT zero-padded rows and the K loop carries no clamps (they cost 317 vs 272 us per launch).
+    constexpr int AX_KT = KT, AX_VKEYS = G::VKEYS, AX_VPLANE = G::VPLANE;
     constexpr bool EXACT = KT <= 10;
-    extern __shared__ __attribute__((aligned(16))) char axs[];
     const int L = sg.L;
-    const int krows = EXACT ? L : AX_KROWS;
-    char* Kh = axs;
-    char* Kl = axs + krows * 128;
-    char* Vh = axs + 2 * krows * 128;
-    char* Vl = Vh + AX_VPLANE;
-    const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
-    // activation row of key slot s of this sequence = s + (s >= off[1] ? A1 : A0); byte offsets inside QKV are 32-bit (the launcher
-    // checks rows x ldq x 4 < 2 GiB), loads go through buffer descriptors: ~6 vector instructions of addressing per K load and
-    // none per V load (its row is wave-uniform -> scalar offset) instead of the 14 of 64-bit pointer arithmetic.
-    const int rA0 = sg.base[0] + b * sg.len[0] - sg.off[0];
-    const int rA1 = sg.nseg > 1 ? sg.base[1] + b * sg.len[1] - sg.off[1] : rA0;
-    const int roff1 = sg.nseg > 1 ? sg.off[1] : 0x7fffffff;
-    const uint32_t rowb = (uint32_t)ldq * 4u;
-    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_cos), 0, L * 128, 0x00020000);
-    const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_sin), 0, L * 128, 0x00020000);
-
-    // ---- stage K (rotate, split, swizzled 8-byte writes; keys >= L are zero rows) and V^T (a wave takes 8-key chunks,
-    //      lane = d: 8 row loads of 256 B each, two 16-byte writes).  Every global load of both is issued before the first
-    //      value is consumed: one exposed round trip per block instead of two.
-    {
-        float vmax = 0.f;                              // range guard: K and V are split from fp32 values here (X16_LIMIT)
-        constexpr int NST = (AX_KROWS * 16 + NTH - 1) / NTH;
-        constexpr int NCHUNK = AX_VKEYS / 8;                          // 40 / 20 chunks of 8 keys
-        constexpr int NCH = (NCHUNK + NTH / 64 - 1) / (NTH / 64);
-        f32x4 kb[NST];
-        float2 cb[NST], sb[NST];
-        float vv[NCH][8];
-        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-        const int kcol = (koff + (tid & 15) * 4) * 4, rcol = (tid & 15) * 8;              // byte offsets inside a row
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            const int key = min((tid >> 4) + (NTH / 16) * k, L - 1);
-            const int row = key + (key >= roff1 ? rA1 : rA0);
-            kb[k] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(q_rs, (int)((uint32_t)row * rowb + (uint32_t)kcol), 0, 0));
-            cb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(c_rs, key * 128 + rcol, 0, 0));
-            sb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(s_rs, key * 128 + rcol, 0, 0));
-        }
-#pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-            const int c = min(wave + (NTH / 64) * cc, NCHUNK - 1);            // chunk 4 t + g (wave-uniform)
-            const int t = c >> 2, g = c & 3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int key = min(32 * t + 16 * (j >> 2) + 4 * g + (j & 3), L - 1);
-                const int row = key + (key >= roff1 ? rA1 : rA0);                       // scalar
-                vv[cc][j] = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(q_rs, (voff + lane) * 4, (int)((uint32_t)row * rowb), 0));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            const int idx = tid + NTH * k;
-            if (idx < krows * 16) {
-                const int key = idx >> 4, c4 = (idx & 15) * 4;
-                const f32x4 kv = kb[k];
-                f32x4 kr;
-                kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
-                kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
-                if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
-                f16x4 hh, ll;
-                split4(kr, hh, ll);
-                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, kr);
-                const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
-                *reinterpret_cast<f16x4*>(Kh + off) = hh;
-                *reinterpret_cast<f16x4*>(Kl + off) = ll;
-            }
-        }
-#pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-            const int c = wave + (NTH / 64) * cc;
-            if (c >= NCHUNK) continue;
-            const int t = c >> 2, g = c & 3;
-            f16x8 hh, ll;
-#pragma unroll
-            for (int q4 = 0; q4 < 2; ++q4) {
-                f32x4 x4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = 4 * q4 + e;
-                    const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
-                    x4[e] = key < L ? vv[cc][j] : 0.f;
-                }
-                f16x4 h4, l4;
-                split4(x4, h4, l4);
-                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, x4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { hh[4 * q4 + e] = h4[e]; ll[4 * q4 + e] = l4[e]; }
-            }
-            const int off = lane * (AX_VKEYS * 2) + (G::vpos(c, lane) << 4);
-            *reinterpret_cast<f16x8*>(Vh + off) = hh;
-            *reinterpret_cast<f16x8*>(Vl + off) = ll;
-        }
-        raise_range_flag(rs, vmax);    // (O is a convex combination of the V rows: covered by the check on V)
-    }
-    __syncthreads();
-
     const int qi = lane & 15, g = lane >> 4;
     const int sw = (qi >> 1) & 7;                      // swizzle of this lane's K row (rows 16 kt + qi)
     const int sw_last = ((L - 1) >> 1) & 7;            // ... and of row L - 1, which stands in for keys >= L
@@ -1901,7 +1865,13 @@ __global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int c4 = 32 * ks + 8 * g + 4 * hf;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
+                f32x4 v;
+                if constexpr (QL2) {       // agent-scope (sc1) load: served by the L2 the same CU's stores were written through to
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    v = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
+                            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000),
+                            (int)(((uint32_t)qrow * (uint32_t)ldq + (uint32_t)(qoff + c4)) * 4u), 0, 16));
+                } else v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
                 const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
                 const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
                 constexpr float QS = 0.125f * 1.44269504088896340736f;
@@ -1994,26 +1964,151 @@ __global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < L) {
+            // O rows through a buffer descriptor with 32-bit byte offsets (the launcher checks rows x ldq x 4 < 2 GiB, and ldo < ldq):
+            // the 64-bit column offsets of plain pointers were loop invariants the 128-register instantiation had to spill
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            const uint32_t ob = (uint32_t)qrow * (uint32_t)ldo * 4u;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 o = oacc[dt];
                 o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
-                const int col = h * ATT_HD + 16 * dt + 4 * g;
                 if (o_split) {
                     f16x4 hh, ll;
                     split4(o, hh, ll);
-                    _Float16* orow = reinterpret_cast<_Float16*>(O + qrow * ldo);
-                    // x16_hi(64 h + 16 dt + 4 g) with dt a compile-time constant: lane part 128 h + 4 g, the rest an immediate (the
-                    // generic shift-and-mask form cost the 128-VGPR kernels six to eight spilled registers)
-                    const int oc = 128 * h + 4 * g + 64 * (dt >> 1) + 16 * (dt & 1);
-                    *reinterpret_cast<f16x4*>(orow + oc) = hh;
-                    *reinterpret_cast<f16x4*>(orow + oc + X16_LO) = ll;
+                    // x16_hi(64 h + 16 dt + 4 g) with dt a compile-time constant: lane part 128 h + 4 g, the rest an immediate
+                    const uint32_t oc = ob + (uint32_t)(128 * h + 4 * g) * 2u;
+                    const uint32_t imm = (uint32_t)(32 * dt) * 2u;                                   // (dt is unrolled: an immediate)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hh), o_rs, (int)(oc + imm), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ll), o_rs, (int)(oc + imm + (uint32_t)X16_LO * 2u), 0, 0);
                 } else {
-                    *reinterpret_cast<f32x4*>(O + qrow * ldo + col) = o;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), o_rs,
+                                                           (int)(ob + (uint32_t)(h * ATT_HD + 4 * g) * 4u + (uint32_t)(16 * dt) * 4u), 0, 0);
                 }
             }
         }
     }
+}
+
+// NTH: threads per block.  KT = 19 runs twelve waves (three per SIMD, 160 VGPRs): the tile loop's MFMA, LDS and vector-ALU phases of
+// three waves interleave better than those of two (227.9 -> 217.7 us per launch); KT = 10 keeps eight (two blocks per CU).
+template <int KT, int NTH = ATT_THREADS>
+__global__ void __launch_bounds__(NTH, KT <= 10 ? 4 : (NTH > 512 ? 3 : 1)) attn_x3_k(const float* __restrict__ QKV, int ldq, int att,
+                                                            const float* __restrict__ rope_cos,
+                                                            const float* __restrict__ rope_sin,
+                                                            float* __restrict__ O, int ldo, int nhead, Segs sg, int o_split,
+                                                            const RunState* __restrict__ rs) {
+    typedef AxGeom<KT> G;
+    constexpr int AX_KT = KT, AX_KROWS = G::KROWS, AX_VKEYS = G::VKEYS, AX_KPLANE = G::KPLANE, AX_VPLANE = G::VPLANE;
+    // KT <= 10 (EXACT): the K planes hold exactly L rows (the launch sizes the dynamic LDS as 2 * 128 L + 2 * VPLANE): for the
+    // nanobody model that is 79 872 B -- two blocks per CU with 4 KB to spare.  (With 160 zero-padded rows the block took 81 920 B,
+    // two blocks filled the CU's 163 840 B exactly, and blocks that started beside a running one produced wrong rows now and then.)
+    // Reads of keys >= L are then redirected to row L - 1 (their scores are masked anyway).  KT = 19 runs one block per CU: its
+    // planes keep 16 KT zero-padded rows and the K loop carries no clamps (they cost 317 vs 272 us per launch).
+    constexpr bool EXACT = KT <= 10;
+    extern __shared__ __attribute__((aligned(16))) char axs[];
+    const int L = sg.L;
+    const int krows = EXACT ? L : AX_KROWS;
+    char* Kh = axs;
+    char* Kl = axs + krows * 128;
+    char* Vh = axs + 2 * krows * 128;
+    char* Vl = Vh + AX_VPLANE;
+    const int b = blockIdx.x / nhead, h = blockIdx.x % nhead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qoff = h * ATT_HD, koff = att + h * ATT_HD, voff = 2 * att + h * ATT_HD;
+    // activation row of key slot s of this sequence = s + (s >= off[1] ? A1 : A0); byte offsets inside QKV are 32-bit (the launcher
+    // checks rows x ldq x 4 < 2 GiB), loads go through buffer descriptors: ~6 vector instructions of addressing per K load and
+    // none per V load (its row is wave-uniform -> scalar offset) instead of the 14 of 64-bit pointer arithmetic.
+    const int rA0 = sg.base[0] + b * sg.len[0] - sg.off[0];
+    const int rA1 = sg.nseg > 1 ? sg.base[1] + b * sg.len[1] - sg.off[1] : rA0;
+    const int roff1 = sg.nseg > 1 ? sg.off[1] : 0x7fffffff;
+    const uint32_t rowb = (uint32_t)ldq * 4u;
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_cos), 0, L * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rope_sin), 0, L * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(O, 0, 0x7fffffff, 0x00020000);
+
+    // ---- stage K (rotate, split, swizzled 8-byte writes; keys >= L are zero rows) and V^T (a wave takes 8-key chunks,
+    //      lane = d: 8 row loads of 256 B each, two 16-byte writes).  Every global load of both is issued before the first
+    //      value is consumed: one exposed round trip per block instead of two.
+    {
+        float vmax = 0.f;                              // range guard: K and V are split from fp32 values here (X16_LIMIT)
+        constexpr int NST = (AX_KROWS * 16 + NTH - 1) / NTH;
+        constexpr int NCHUNK = AX_VKEYS / 8;                          // 40 / 20 chunks of 8 keys
+        constexpr int NCH = (NCHUNK + NTH / 64 - 1) / (NTH / 64);
+        f32x4 kb[NST];
+        float2 cb[NST], sb[NST];
+        float vv[NCH][8];
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const int kcol = (koff + (tid & 15) * 4) * 4, rcol = (tid & 15) * 8;              // byte offsets inside a row
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int key = min((tid >> 4) + (NTH / 16) * k, L - 1);
+            const int row = key + (key >= roff1 ? rA1 : rA0);
+            kb[k] = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(q_rs, (int)((uint32_t)row * rowb + (uint32_t)kcol), 0, 0));
+            cb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(c_rs, key * 128 + rcol, 0, 0));
+            sb[k] = __builtin_bit_cast(float2, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(s_rs, key * 128 + rcol, 0, 0));
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int c = min(wave + (NTH / 64) * cc, NCHUNK - 1);            // chunk 4 t + g (wave-uniform)
+            const int t = c >> 2, g = c & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = min(32 * t + 16 * (j >> 2) + 4 * g + (j & 3), L - 1);
+                const int row = key + (key >= roff1 ? rA1 : rA0);                       // scalar
+                vv[cc][j] = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(q_rs, (voff + lane) * 4, (int)((uint32_t)row * rowb), 0));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int idx = tid + NTH * k;
+            if (idx < krows * 16) {
+                const int key = idx >> 4, c4 = (idx & 15) * 4;
+                const f32x4 kv = kb[k];
+                f32x4 kr;
+                kr[0] = kv[0] * cb[k].x - kv[1] * sb[k].x; kr[1] = kv[0] * sb[k].x + kv[1] * cb[k].x;
+                kr[2] = kv[2] * cb[k].y - kv[3] * sb[k].y; kr[3] = kv[2] * sb[k].y + kv[3] * cb[k].y;
+                if (!EXACT && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};       // padding rows
+                f16x4 hh, ll;
+                split4(kr, hh, ll);
+                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, kr);
+                const int off = key * 128 + ((((c4 >> 3) ^ ((key >> 1) & 7))) << 4) + (c4 & 7) * 2;
+                *reinterpret_cast<f16x4*>(Kh + off) = hh;
+                *reinterpret_cast<f16x4*>(Kl + off) = ll;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int c = wave + (NTH / 64) * cc;
+            if (c >= NCHUNK) continue;
+            const int t = c >> 2, g = c & 3;
+            f16x8 hh, ll;
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                f32x4 x4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * q4 + e;
+                    const int key = 32 * t + 16 * (j >> 2) + 4 * g + (j & 3);
+                    x4[e] = key < L ? vv[cc][j] : 0.f;
+                }
+                f16x4 h4, l4;
+                split4(x4, h4, l4);
+                if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, x4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hh[4 * q4 + e] = h4[e]; ll[4 * q4 + e] = l4[e]; }
+            }
+            const int off = lane * (AX_VKEYS * 2) + (G::vpos(c, lane) << 4);
+            *reinterpret_cast<f16x8*>(Vh + off) = hh;
+            *reinterpret_cast<f16x8*>(Vl + off) = ll;
+        }
+        raise_range_flag(rs, vmax);    // (O is a convex combination of the V rows: covered by the check on V)
+    }
+    __syncthreads();
+
+    attn_x3_tiles<KT, NTH, false>(Kh, Kl, Vh, Vl, QKV, ldq, qoff, rope_cos, rope_sin, o_rs, ldo, b, h, sg, o_split, rs, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------

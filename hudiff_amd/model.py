@@ -61,7 +61,7 @@ class _Denoiser:
                  n_region, r_embedding, r_model, n_pos_model, max_len, sum_d_model, dual_layers,
                  att_model, dim_feedforward, nhead, cs_layers, n_side=3, s_embedding=4, s_model=None,
                  rank=None, n_frozen_embs=None, padding_idx=None, causal=False, dropout=0.0, slim=True,
-                 activation="relu", down_embed=False, timesteps=None, device=0, precision=None):
+                 activation="relu", down_embed=False, timesteps=None, device=0, precision=None, options=None):
         if rank is not None or n_frozen_embs is not None or causal or not slim or down_embed or padding_idx is not None:
             raise NotImplementedError("only the configuration HuDiff ships (rank=None, causal=False, slim=True, "
                                       "down_embed=False, padding_idx=None) is implemented")
@@ -105,6 +105,32 @@ class _Denoiser:
         self._loaded = False
         self._seen_fallbacks = (0, 0)
         self.device_index = int(device)
+        # tuning options (include/hudiff_hip.h "tuning options"): {name: value}, e.g. {"lanes": 1, "lnsync_level": 0}
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    # -- tuning options (hd_set_option / hd_get_option) --------------------------------------------
+    @staticmethod
+    def _option_id(name):
+        if isinstance(name, str):
+            key = name.lower().removeprefix("hd_opt_")
+            if key not in L.OPTIONS:
+                raise ValueError(f"unknown option {name!r}; known: {sorted(L.OPTIONS)}")
+            return L.OPTIONS[key]
+        return int(name)
+
+    def set_option(self, name, value):
+        """An explicit choice of a kernel-selecting knob; wins over the HUDIFF_* environment variable of the same meaning."""
+        L.check(self._lib.hd_set_option(self._h, self._option_id(name), int(value)))
+        return self
+
+    def get_option(self, name):
+        v = C.c_int64()
+        L.check(self._lib.hd_get_option(self._h, self._option_id(name), C.byref(v)))
+        return int(v.value)
+
+    def options(self):
+        return {n: self.get_option(i) for n, i in L.OPTIONS.items()}
 
     # -- nn.Module-shaped surface ---------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -302,12 +328,16 @@ class _Denoiser:
     def debug_fail_next_lnsync(self):
         L.check(self._lib.hd_debug_fail_next_lnsync(self._h))
 
+    def debug_scatter_lnsync(self, on=True):
+        L.check(self._lib.hd_debug_scatter_lnsync(self._h, 1 if on else 0))
+
     def debug_stop_after(self, stage):
         L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
 
     def debug_read(self, name, B):
-        width = {"FEAT": "sum_d_model", "Y": "sum_d_model", "AT": "sum_d_model"}.get(name, "d_model")
-        out = np.empty((B, self.max_len, self.config[width]), dtype=np.float32)
+        width = {"FEAT": "sum_d_model", "Y": "sum_d_model", "AT": "sum_d_model", "O": "att_model"}.get(name, "d_model")
+        w = 3 * self.config["att_model"] if name == "QKV" else self.config[width]
+        out = np.empty((B, self.max_len, w), dtype=np.float32)
         L.check(self._lib.hd_debug_read(self._h, name.encode(), B, L.ptr(out, C.c_float), out.size))
         return out
 
@@ -335,14 +365,14 @@ class NanoAntiTFNet(_Denoiser):
                          cs_layers, **kw)
 
 
-def model_selected(config, pretrained_model=None, tokenizer=None, device=0, precision=None):
+def model_selected(config, pretrained_model=None, tokenizer=None, device=0, precision=None, options=None):
     """utils/train_utils.py:43-55 for the two inference models (the training-only wrappers are out of scope)."""
     name = _get(config, "name")
     params = dict(_get(config, "model"))
     if name == "trans_oadm":
-        return AntiTFNet(**params, device=device, precision=precision)
+        return AntiTFNet(**params, device=device, precision=precision, options=options)
     if name == "nano":
-        return NanoAntiTFNet(**params, device=device, precision=precision)
+        return NanoAntiTFNet(**params, device=device, precision=precision, options=options)
     raise NotImplementedError(f"config.name={name!r}: only 'trans_oadm' and 'nano' are sampling models")
 
 

@@ -47,7 +47,8 @@
 extern "C" {
 #endif
 
-#define HD_ABI_VERSION 1      /* layout of HdConfig; round 4 added entry points (hd_set_precision, hd_precision_report, hd_precision_reset) only */
+#define HD_ABI_VERSION 1      /* layout of HdConfig; rounds 4-5 added entry points only (hd_set_precision, hd_precision_report, hd_precision_reset,
+                                 hd_set_option, hd_get_option, hd_debug_scatter_lnsync) */
 
 typedef enum HdStatus {
     HD_OK = 0,
@@ -215,6 +216,46 @@ HdStatus hd_precision_report(HdModel* m, HdPrecisionInfo* out, size_t size);
 HdStatus hd_precision_info(HdModel* m, int32_t* split_built, int32_t* split_in_use, int64_t* range_fallbacks);
 /* Puts a handle whose guards switched kernels off back on its configured route (between calls; HD_ERR_STATE inside a session). */
 HdStatus hd_precision_reset(HdModel* m);
+/* ---- tuning options ----------------------------------------------------------------------------------
+ * The knobs that SELECT KERNELS or change how a batch is scheduled are part of the ABI (round 5; rounds 1-4 read them from the
+ * environment only).  Every option has a library default (the value the published numbers use).  Precedence, as for the precision
+ * route: an explicit hd_set_option wins; an option nobody set takes the environment variable named beside it if that is exported
+ * when hd_create runs, else the default.  hd_set_option is legal between calls (HD_ERR_STATE inside a sampling session; options
+ * marked [create] only before hd_finalize); it drops the handle's captured graphs.  Values outside [lo, hi] -> HD_ERR_INVALID.
+ * None of them changes results beyond the last-ulp reassociation documented in INTEGRATION.md (tile shapes share one K order).     */
+typedef enum HdOption {
+    HD_OPT_LANES = 0,               /* HUDIFF_LANES            2     [1, 4]   lanes (stream + workspace + graph) a sampling batch is split into          */
+    HD_OPT_LANE_MIN_ROWS = 1,       /* HUDIFF_LANE_MIN_B       16    [2, ..]  fewest rows of a batch that is split into lanes                           */
+    HD_OPT_SPLIT_MIN_ROWS = 2,      /* HUDIFF_X3_ROWS          128   [1, ..]  fewest activation rows of a launch that takes the split-precision kernels   */
+    HD_OPT_BIG_MIN_ROWS = 3,        /* HUDIFF_BIG_ROWS         8192  [1, ..]  fewest activation rows of a launch that takes the fp32 128-row-tile kernels */
+    HD_OPT_LNSYNC_LEVEL = 4,        /* HUDIFF_X3_LNSYNC        2     [0, 2]   split ByteNet GEMMs normalise their own output: 0 no (ln_apply_k passes),
+                                                                             1 the two inner GEMMs of a block, 2 the block's last GEMM as well           */
+    HD_OPT_TAIL_FORM = 5,           /* HUDIFF_TAIL             2     {0, 2}   pruned tail of a sampling step: 0 twelve separate launches, 2 five sliced ones */
+    HD_OPT_TAIL_MAX_ROWS = 6,       /* HUDIFF_TAIL_MAX_B       64    [0, ..]  largest lane that takes the sliced tail                                    */
+    HD_OPT_SMALL_GRID = 7,          /* HUDIFF_X3_SMALL_GRID    300   [0, ..]  largest 128 x 128 grid of a split GEMM that takes 64 x 128 tiles instead    */
+    HD_OPT_TINY_GRID = 8,           /* HUDIFF_X3_TINY_GRID     150   [0, ..]  largest 64 x 128 grid that takes 32 x 128 tiles instead                    */
+    HD_OPT_LOADER_WAVES = 9,        /* HUDIFF_X3_LOADERS       1     [0, 1]   32 x 128 blocks carry four DMA-issuing waves while they fit one per CU      */
+    HD_OPT_TINY_STAGES = 10,        /* HUDIFF_X3_TINY_NS       3     [2, 3]   LDS stages of the 32 x 128 split tiles                                     */
+    HD_OPT_SMALL_STAGES = 11,       /* HUDIFF_X3_SMALL_NS      0     {0,2,3}  LDS stages of the 64 x 128 split tiles; 0 = three up to the grid below      */
+    HD_OPT_SMALL_STAGES3_MAX_GRID = 12, /* HUDIFF_X3_SMALL_NS3_MAX 256 [0, ..]                                                                           */
+    HD_OPT_ATTN_QSPLIT_MAX_GRID = 13,   /* HUDIFF_ATTN_QSPLIT_MAX 128 [0, ..] largest (sequence, head) grid whose query tiles are shared by two workgroups */
+    HD_OPT_ATTN_WAVES = 14,         /* HUDIFF_ATTN_WAVES       12    {8, 12}  waves of the split attention core for L in (288, 304]                       */
+    HD_OPT_LOOP_GRAPH = 15,         /* HUDIFF_LOOP_GRAPH       0     [0, 1]   1 = every hd_sample_run behaves as if HD_LOOP_GRAPH were set                 */
+    HD_OPT_PRUNE_VALUE_VIA_ROWS = 16,   /* HUDIFF_PRUNE_V      1     [0, 1]   pruned last block: value side through the input rows (no V projection)      */
+    HD_OPT_SPLIT_TILE = 17,         /* HUDIFF_X3_TILE          0     {0,128,256,512} force the big split GEMM tile: 128 x 128 / 256 x 128 / 256 x 256; 0 = by shape */
+    HD_OPT_GEMM_SMALL_TILES = 18,   /* HUDIFF_GEMM_SMALL       1536  [0, ..]  fp32 launches with fewer 128-row tiles take 64 x 128 tiles                  */
+    HD_OPT_STORE_NT = 19,           /* HUDIFF_ST_NT            0     [0, 1]   non-temporal epilogue stores in the fp32 GEMMs (the split GEMMs always use them) */
+    HD_OPT_SPLIT_LAYER_MASK = 20,   /* HUDIFF_X3_MASK          3     [0, 3]   [create] bit 0 ByteNet blocks, bit 1 attention blocks get split weight images */
+    HD_OPT_SPLIT_ATTN = 21,         /* HUDIFF_X3_ATTN          1     [0, 1]   split route: 0 keeps the fp32 attention core                                */
+    HD_OPT_FUSED_ATTN = 22,         /* HUDIFF_FUSED_ATTN       1     [0, 1]   split route: the Q|K|V projection runs inside the attention kernel (one workgroup per
+                                                                             (sequence, head group), K / V never leave the CU); 0 = projection GEMM + attention core    */
+    HD_OPT_FUSED_ATTN_MIN_GRID = 23,/* HUDIFF_FUSED_ATTN_MIN_GRID 128 [0, ..] fewest (sequence, head group) workgroups -- over all lanes -- for which the fused
+                                                                             form is taken (below, the two-launch form's finer tiles fill the chip better)        */
+    HD_OPT_COUNT = 24
+} HdOption;
+HdStatus hd_set_option(HdModel* m, int32_t option, int64_t value);
+HdStatus hd_get_option(HdModel* m, int32_t option, int64_t* value);
+
 /* Device facts for the bench JSON. */
 HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
 
@@ -227,6 +268,10 @@ HdStatus hd_debug_stop_after(HdModel* m, int32_t stage);
  * its repeat path can be tested; cleared when the guard has fired. */
 HdStatus hd_debug_fail_next_lnsync(HdModel* m);
 HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float* out, int64_t n_floats);
+/* on != 0: the ln_sync launches deal the N tiles of an M tile to DIFFERENT XCDs (consecutive workgroup ids) instead of one XCD's
+ * consecutive slots, so that the cross-XCD path of the meeting (write-through partials, agent-scope loads) is the one that runs;
+ * results must be bit-identical to the normal placement and hd_precision_report then says lnsync_cross_xcd = 1. */
+HdStatus hd_debug_scatter_lnsync(HdModel* m, int32_t on);
 
 #ifdef __cplusplus
 }

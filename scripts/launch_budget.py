@@ -43,7 +43,8 @@ def main():
             rows.append((float(m.group(2)), int(m.group(3)), m.group(4).strip()))
     # name the launches by position: 6 encoder blocks, 6 dual-conv blocks, attention blocks (the last one pruned)
     out = []
-    gem = [r for r in rows if "gemm" in r[2] and r[1] >= 500 or "attn_x3_k" in r[2] or "attn_k<" in r[2]]
+    gem = [r for r in rows if "gemm" in r[2] and r[1] >= 500 or "attn_x3_k" in r[2] or "attn_k<" in r[2] or "qkv_attn_x3_k" in r[2]]
+    fused = any("qkv_attn_x3_k" in r[2] for r in rows)        # round 5: the Q|K|V projection runs inside the attention kernel (one launch)
     names = []
     for n in range(6):
         names += [("enc PFF1 256->128", gemm(d, dh), (d + dh)), ("enc tap GEMM 7x128->128", gemm(dh, dh, 7), (dh + dh)),
@@ -53,15 +54,18 @@ def main():
                   ("PFF3 384->768 (+x)", gemm(Dh, D), (Dh + D + D + (D if x3 else 0)))]
     att = 4.0 * L * L * 64 * H * 256
     blk = []
+    def qkv_att(tag):
+        # fused: the layer input is read once, O written once (Q round trip: one third of Q|K|V written and read back, L2-resident)
+        if fused:
+            return [(f"Q|K|V{tag} + attention core (fused)", gemm(D, 3 * A) + att, (D + A + 2 * A))]
+        return [(f"Q|K|V 768->1536{tag}", gemm(D, 3 * A), (D + 3 * A)), ("attention core", att, (3 * A + A))]
     for n in range(5):
         last = n == 4
-        blk += [("Q|K|V 768->1536", gemm(D, 3 * A), (D + 3 * A)), ("attention core", att, (3 * A + A)),
-                ("out-projection 512->768 (+x)", gemm(A, D), (A + D + D + (D if x3 else 0)))]
+        blk += qkv_att("") + [("out-projection 512->768 (+x)", gemm(A, D), (A + D + D + (D if x3 else 0)))]
         if last:
             blk += [("K of the pruned attention 768->512", gemm(D, A), (D + A))]
             break
-        blk += [("Q|K|V 768->1536 (LN folded)", gemm(D, 3 * A), (D + 3 * A)), ("attention core", att, (3 * A + A)),
-                ("out-projection 512->768 (+x)", gemm(A, D), (A + D + D + (D if x3 else 0))),
+        blk += qkv_att(" (LN folded)") + [("out-projection 512->768 (+x)", gemm(A, D), (A + D + D + (D if x3 else 0))),
                 ("FF1 768->256", gemm(D, Fd), (D + Fd)), ("FF2 256->768 (+x)", gemm(Fd, D), (Fd + D + D + (D if x3 else 0)))]
     names += blk
     if len(names) != len(gem):
