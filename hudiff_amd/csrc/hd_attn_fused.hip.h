@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
             load_x(At, aoff0, c0, c3, a0h, a0l);
             // the other stage was read in tile kt - 1 and every wave is past that tile's barrier: its DMA goes out behind this tile's
             // first fragment requests (they are what the first MFMAs wait for)
+            // (issuing the DMA in two or three portions over the MFMA steps instead changes nothing: 716 / 715 / 720 us per launch, NOTES.md D)
             if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
             load_x(At, aoff0, c3, c2, b0h, b0l);
             __builtin_amdgcn_sched_barrier(0);
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
             __builtin_amdgcn_sched_barrier(0);
             mm(sw_c, c3, c2, b0h, b0l, w0h, w0l);
             __builtin_amdgcn_sched_barrier(0);
+
             load_x(At, aoff1, c3, c2, b1h, b1l);
             __builtin_amdgcn_sched_barrier(0);
             mm(sw_c, c0, c3, a1h, a1l, w1h, w1l);

@@ -285,9 +285,6 @@ __device__ __forceinline__ f32x2 pro_f2(f32x2 x, float mean, float rstd, f32x2 g
 #ifndef HD_SPLIT4_MODE
 #define HD_SPLIT4_MODE 0
 #endif
-#ifndef HD_X3_PRE
-#define HD_X3_PRE 1          // A/B aid: 0 builds gemm_x3_k without the residual prefetch ahead of the K loop
-#endif
 typedef _Float16 hd_f16x4 __attribute__((ext_vector_type(4)));
 // X16 row format (GemmP): half index of the HIGH part of column c; its low part sits X16_LO halfs further.  Columns c .. c + 3 of a
 // float4 (c % 4 == 0) stay contiguous.  Round 5: groups of SIXTEEN columns -- 16 fp16 high parts, then 16 low parts = 64 bytes -- so that
@@ -332,14 +329,12 @@ __host__ __device__ __forceinline__ int epi_needs(const GemmP& p) {
            (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0) |
            (p.ln_sync ? EPI_LNSYNC : 0);
 }
-// rows of a wave's 32-row pass that one wave instruction covers in the epilogue's float4 layout (WTN / 4 lanes per row)
-__host__ __device__ constexpr int epi_rpi(int wtn) { return 64 / (wtn / 4); }
-// PRE: the residual values of the block's output tile were requested BEFORE the K loop (gemm_x3_k: `pre`, one float4 per (pass, row
-// group) in this function's own lane layout) -- their HBM round trips travel under the K loop instead of opening every 32-row pass.
-template <int BM, int BN, int WM, int WN, int F = EPI_ALL, bool PRE = false>
+// (Requesting a block's residual values BEFORE its K loop -- 64 registers in the 128 x 128 instantiation, so that their HBM round trips
+//  travel under the loop instead of opening every 32-row pass -- was built and measured in round 5: 99.4 vs 99.9 sequences/s, removed.)
+template <int BM, int BN, int WM, int WN, int F = EPI_ALL>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
-                                              int by, const f32x4 (&pre)[PRE ? BM / WM / 32 : 1][PRE ? 32 / epi_rpi(BN / WN) : 1]) {
+                                              int by) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
@@ -422,10 +417,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
         // while the accumulators are transposed through LDS instead of serialising load -> store per row
         f32x4 rres[32 / RPI];
-        if constexpr (PRE) {
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; ++it) rres[it] = pre[i][it];
-        } else if (has_resid) {
+        if (has_resid) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int g0 = wrow0 + 32 * i + it * RPI;                       // uniform
@@ -1011,8 +1003,7 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : (NBUF == 1 ? 3 : 2)) gemm_
 
     // EPI: the epilogue features this instantiation carries (chosen by the host, launch_gemm_t: one epilogue per kernel -- four
     // copies behind an in-kernel branch, as gemm_x3_k has them, push this 128-VGPR kernel into scratch: 600 spilled registers)
-    const f32x4 no_pre[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
-    gemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by, no_pre);
+    gemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, reinterpret_cast<const float2*>(smem + WORK_FLOATS), seg, seg_rows, rbase, Lc, m0, n0, by);
 }
 
 
@@ -1187,43 +1178,6 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Residual prefetch (PRE; the 128 x 128 instantiation: two blocks per CU leave 256 registers per wave).  The N = 768 projections
-    // (out-projection, PFF3, FF2) are bound by HBM round trips, not bytes: their epilogue used to open each 32-row pass with the
-    // residual loads of that pass (two exposed HBM latencies per wave, and no HBM reads at all while the K loop runs on L2-resident
-    // operands).  Every lane now asks for all the residual float4s it will add -- exactly the elements it overwrites, so an aliased
-    // output (C == resid) is safe -- before the first DMA; they are older than every DMA on the in-order vmcnt, so the first k tile's
-    // wait covers them (once per block), and they arrive while the other co-resident block computes.
-    constexpr bool PRE = HD_X3_PRE && BM == 128 && BN == 128 && NW == 4 && LW == 0;
-    constexpr int PRE_TM = PRE ? TM : 1, PRE_IT = PRE ? 32 / epi_rpi(WTN) : 1;
-    f32x4 pre[PRE_TM][PRE_IT];
-    if constexpr (PRE) {
-        constexpr int LPR = WTN / 4, RPI = 64 / LPR;
-        const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
-        const int col = n0 + wn * WTN + e_c4;
-        const bool col_ok = col < p.N;
-        const uint32_t r_vo = (uint32_t)((e_r * p.ldr + (col_ok ? col : 0)) * 4);
-        const int wrow0 = m0 + wm * WTM;
-        if (p.resid != nullptr) {                                               // (uniform)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int g0 = wrow0 + 32 * i + it * RPI;                   // uniform
-                    const bool ok = g0 + e_r < seg_rows && col_ok;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float*>(p.resid) + (long)(rbase + g0) * p.ldr, 0, 0x7FFFFFFF, 0x00020000);
-                    pre[i][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : BUF_OOB), 0, 0));
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) pre[i][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    } else {
-        pre[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
     // W fragment of row r = (wave part) + 32 t + (lane & 31), k step ks, k octet g = lane >> 5: chunk 2 ks + g sits at slot
     // chunk ^ ((r >> 2) & 3) of its 64-byte plane row; A fragment (X16 groups of 16 columns: hi k 0-7, hi k 8-15, lo k 0-7, lo k 8-15 per
     // k step): high-part chunk 4 ks + g (low part: + 2) at slot chunk ^ ((r >> 1) & 7) of the 128-byte row.  The wave part and 32 t do
@@ -1313,7 +1267,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
     const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
     const int need = p.x3_abl & 64 ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);
-#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3, PRE>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by, pre)
+#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
     if (need & EPI_LNSYNC) {
         // (only the 4-wave 128 x 128 instantiation is ever launched with ln_sync; the others keep the code out)
         if constexpr (NW == 4 && EPISET != 1) {

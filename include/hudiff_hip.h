@@ -232,7 +232,7 @@ typedef enum HdOption {
                                                                              1 the two inner GEMMs of a block, 2 the block's last GEMM as well           */
     HD_OPT_TAIL_FORM = 5,           /* HUDIFF_TAIL             2     {0, 2}   pruned tail of a sampling step: 0 twelve separate launches, 2 five sliced ones */
     HD_OPT_TAIL_MAX_ROWS = 6,       /* HUDIFF_TAIL_MAX_B       64    [0, ..]  largest lane that takes the sliced tail                                    */
-    HD_OPT_SMALL_GRID = 7,          /* HUDIFF_X3_SMALL_GRID    300   [0, ..]  largest 128 x 128 grid of a split GEMM that takes 64 x 128 tiles instead    */
+    HD_OPT_SMALL_GRID = 7,          /* HUDIFF_X3_SMALL_GRID    320   [0, ..]  largest 128 x 128 grid of a split GEMM that takes 64 x 128 tiles instead    */
     HD_OPT_TINY_GRID = 8,           /* HUDIFF_X3_TINY_GRID     150   [0, ..]  largest 64 x 128 grid that takes 32 x 128 tiles instead                    */
     HD_OPT_LOADER_WAVES = 9,        /* HUDIFF_X3_LOADERS       1     [0, 1]   32 x 128 blocks carry four DMA-issuing waves while they fit one per CU      */
     HD_OPT_TINY_STAGES = 10,        /* HUDIFF_X3_TINY_NS       3     [2, 3]   LDS stages of the 32 x 128 split tiles                                     */
