@@ -38,7 +38,8 @@ struct QkvAttnP {
     float* O; int ldo;                             // attention output rows, X16 split form [rows, att]
     int nhead; Segs sg; const RunState* rs;
     int abl;                                       // probes only (HUDIFF_QA_ABL): 1 no MFMAs in the projection, 2 no operand DMA after the first tile,
-                                                   // 4 no attention core, 8 no hand-over of K / V into the planes
+                                                   // 4 no attention core, 8 no hand-over of K / V into the planes, 32 phase time stamps (100 MHz
+                                                   // ticks since kernel entry, per wave of the head-0 workgroups) into the unused V third of QKV
 };
 
 constexpr int QA_THREADS = 768, QA_WAVES = 12;
@@ -56,12 +57,13 @@ struct QaGeom {
     static constexpr int RSTD_OFF = 2 * STAGE;                 // float rstd[ROWS] behind the two stages
     // K / V planes of head hh at hh * PLANES (exact-length K planes for the short model, as attn_x3_k<10> has them)
     __host__ __device__ static constexpr int planes(int L) { return 2 * (KT <= 10 ? L : G::KROWS) * 128 + 2 * G::VPLANE; }
+    static constexpr int BIAS_OFF = RSTD_OFF + ROWS * 4;       // float bias[COLS] of the workgroup's columns, in the order of the weight rows in LDS
     __host__ __device__ static constexpr int smem(int L) {
-        const int a = NH * planes(L), b = RSTD_OFF + ROWS * 4;
+        const int a = NH * planes(L), b = BIAS_OFF + COLS * 4;
         return a > b ? a : b;
     }
     static_assert(RT % RG == 0 && CT * RG == QA_WAVES && W_PIECES % QA_WAVES == 0 && TM == 5, "tile / wave split");
-    static_assert(RSTD_OFF + ROWS * 4 <= LDS_PER_CU && NH * (2 * G::KROWS * 128 + 2 * G::VPLANE) <= LDS_PER_CU + (KT <= 10 ? 4096 : 0), "LDS");
+    static_assert(BIAS_OFF + COLS * 4 <= LDS_PER_CU && NH * (2 * G::KROWS * 128 + 2 * G::VPLANE) <= LDS_PER_CU + (KT <= 10 ? 4096 : 0), "LDS");
 };
 
 template <int KT, int NH>
@@ -87,13 +89,25 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
     const int rA1 = p.sg.nseg > 1 ? p.sg.base[1] + b * p.sg.len[1] - p.sg.off[1] : rA0;
     const int roff1 = p.sg.nseg > 1 ? p.sg.off[1] : 0x7fffffff;
     const int nkt = p.ldx / X3_BK;
+    const unsigned long long t_entry = (p.abl & 32) ? wall_clock64() : 0ull;
+    auto stamp = [&](int k) {                          // probe (abl bit 5): phase k of this wave, head-0 workgroups only
+        if ((p.abl & 32) && h0 == 0 && lane == 0)
+            p.QKV[(long)(rA0 + p.sg.off[0]) * p.ldq + 2 * p.att + wave * 8 + k] = (float)(wall_clock64() - t_entry);
+    };
     float* rstd_s = reinterpret_cast<float*>(qas + Q::RSTD_OFF);
-    // folded LayerNorm: rstd of every row of the sequence (visible after the first barrier); called once the first tile's DMA is in flight
+    // rstd of every row of the sequence for a folded LayerNorm (1 without one) and the bias of the workgroup's columns, into LDS (visible
+    // after the first barrier; called once the first tile's DMA is in flight): step 1 of the hand-over then reads them with vector LDS
+    // reads instead of opening with a global round trip (bias) and 80 dependent scalar reads behind a branch each (V waves, round 5 stamps:
+    // 6.0 us of step 1 against 2.3 us for the K waves)
+    float* bias_s = reinterpret_cast<float*>(qas + Q::BIAS_OFF);
     auto row_rstd = [&]() {
-        if (!p.ln_fold) return;
+        if (tid < Q::COLS) {
+            const int hh_ = tid / 192, part_ = (tid % 192) / 64, within = tid % 64;
+            bias_s[tid] = p.bias[part_ * p.att + (h0 + hh_) * ATT_HD + within];
+        }
         for (int r = tid; r < Q::ROWS; r += QA_THREADS) {
             float v = 1.f;
-            if (r < L) {
+            if (p.ln_fold && r < L) {
                 const long grow = r + (r >= roff1 ? rA1 : rA0);
                 v = p.spart ? merge_row_stat(p.spart, p.spw, p.spart_rows, p.ldx, grow).y : p.stats[grow].y;
             }
@@ -229,26 +243,28 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
             lds_barrier();                             // ... everybody's part of it; everybody is done reading tile kt
         }
 
+        stamp(0);                                      // K loop done
         // ---- hand-over, step 1: finish the values in place (scale, rstd of a folded LayerNorm, bias); Q rows go out -----------
-        if constexpr (PART == 2) {                     // V: rows x d
-            const float bv = p.bias[PART * p.att + hcol + 32 * half + l31];
+        if constexpr (PART == 2) {                     // V: rows x d -- a lane holds rows 8 j + 4 khalf + (0 .. 3) of each tile: one 16-byte read of their rstd
+            const float bv = bias_s[ct * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = 32 * (rg * TM + i) + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    float v = acc[i][r] * sc;
-                    if (p.ln_fold) v *= rstd_s[m];
-                    acc[i][r] = v + bv;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(rstd_s + 32 * (rg * TM + i) + 8 * j + 4 * khalf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][4 * j + e] = acc[i][4 * j + e] * sc * rs4[e] + bv;
                 }
+                asm volatile("" : "+v"(acc[i]));       // (finished HERE: left alone the compiler sinks the arithmetic behind the barrier, into
+                                                       // step 2, and carries all twenty rstd reads across it: 80 registers, spills)
+            }
         } else {                                       // Q, K: d x rows
             f32x4 bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + PART * p.att + hcol + 32 * half + 8 * j + 4 * khalf);
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bias_s + ct * 32 + 8 * j + 4 * khalf);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int key = 32 * (rg * TM + i) + l31;
-                const float rs_k = p.ln_fold ? rstd_s[key] : 1.f;
+                const float rs_k = rstd_s[32 * (rg * TM + i) + l31];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * sc * rs_k + bv[r >> 2][r & 3];
             }
@@ -268,9 +284,12 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
                 }
             }
         }
-        __syncthreads();                               // every wave has left the K loop and read its rstd: the planes may overwrite both
+        stamp(1);                                      // step 1 done
+        lds_barrier();                                 // every wave has left the K loop and read its rstd: the planes may overwrite both
+                                                       // (LDS-only: the Q stores and the table loads stay in flight; the barrier behind step 2 drains them)
 
         // ---- hand-over, step 2: K (rotated, split) and V (split) into the LDS images attn_x3_tiles reads (AxGeom<KT>) ---------
+        stamp(2);                                      // past barrier 1
         char* planes = qas + hh * Q::planes(L);
         char* Kh = planes;
         char* Kl = planes + krows * 128;
@@ -280,7 +299,8 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
         if (p.abl & 8) {
         } else if constexpr (PART == 1) {
             // cos, sin, cos, sin of the two RoPE pairs of head dimensions d0 .. d0 + 3 (one 16-byte load); the table rows of tile i + 1 are
-            // requested before tile i is rotated (two tiles = 32 registers in flight: five serial round trips were most of this phase)
+            // requested before tile i is rotated (two tiles = 32 registers in flight: five serial round trips were most of this phase;
+            // requesting tiles 0 and 1 in front of step 1 measured the same and spills)
             f32x4 cs[2][4];
             auto load_cs = [&](int i, f32x4 (&dst)[4]) {
                 const int key = 32 * (rg * TM + i) + l31;
@@ -303,7 +323,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
                     f32x4 kr;
                     kr[0] = k0 * c4[0] - k1 * c4[1]; kr[1] = k0 * c4[1] + k1 * c4[0];
                     kr[2] = k2 * c4[2] - k3 * c4[3]; kr[3] = k2 * c4[3] + k3 * c4[2];
-                    if (key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};                // padding rows (KT = 19: the planes hold 16 KT rows)
+                    if (32 * (rg * TM + i) + 32 > L && key >= L) kr = f32x4{0.f, 0.f, 0.f, 0.f};      // padding rows (only the last tile has any; KT = 19: the planes hold 16 KT rows)
                     f16x4 hv, lv;
                     split4(kr, hv, lv);
                     if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, kr);
@@ -323,9 +343,11 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int o = 8 * j + 4 * khalf;                             // first of four consecutive keys inside the block
-                    f32x4 x4;
+                    f32x4 x4 = {acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
+                    if (32 * t + 32 > L) {                                       // (wave-uniform: only the last tile holds keys >= L)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x4[e] = (32 * t + o + e < L) ? acc[i][4 * j + e] : 0.f;
+                        for (int e = 0; e < 4; ++e) x4[e] = (32 * t + o + e < L) ? x4[e] : 0.f;
+                    }
                     f16x4 hv, lv;
                     split4(x4, hv, lv);
                     if (HD_GUARD_MASK & 8) vmax = absmax4(vmax, x4);
@@ -338,7 +360,9 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
             }
         }
         if constexpr (PART != 0) raise_range_flag(p.rs, vmax);
+        stamp(3);                                      // step 2 done
         __syncthreads();                               // planes complete; the Q stores of this workgroup have drained (vmcnt(0) in front of the barrier)
+        stamp(4);                                      // past barrier 2
     };
     if (part == 0) wave_program(std::integral_constant<int, 0>{});
     else if (part == 1) wave_program(std::integral_constant<int, 1>{});
@@ -353,6 +377,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
         attn_x3_tiles<KT, QA_THREADS, true>(pl, pl + krows * 128, pl + 2 * krows * 128, pl + 2 * krows * 128 + G::VPLANE, p.QKV, p.ldq,
                                             (h0 + hx) * ATT_HD, p.rope_cos, p.rope_sin, o_rs, p.ldo, b, h0 + hx, p.sg, 1, p.rs, lane, wave);
     }
+    stamp(5);                                          // attention done
 }
 
 }  // namespace hd
