@@ -10,6 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhudiff_hip.so")
 SOURCES = [os.path.join(CSRC, "hd_api.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"), os.path.join(CSRC, "hd_tail_fused.hip.h"),
+                  os.path.join(CSRC, "hd_attn_fused.hip.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hudiff_hip.h")]
 
 

@@ -1188,9 +1188,10 @@ static size_t lds_request(int bytes, int threads) {
     return (size_t)(no_pad ? bytes : lds_safe_request(bytes, threads));
 }
 
+// split_only (x3, out_split set): nobody reads `out` as fp32 rows -- the out-projection writes the split copy alone (GemmP::c_split).
 static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, const float* x, bool ln,
                             const float* resid, float* out, bool want_out_stats, bool x3 = false,
-                            const float* x_split = nullptr, float* out_split = nullptr) {
+                            const float* x_split = nullptr, float* out_split = nullptr, bool split_only = false) {
     hipStream_t st = cur(m).stream;
     const int D = m->D, A = m->A;
     GemmP p = base_gemm(m, sg);
@@ -1221,6 +1222,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
         p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
         p.resid = resid; p.ldr = D;
         use_x3(p, w.wox); p.C2 = out_split;
+        if (split_only && out_split) { p.C = out_split; p.c_split = 1; p.C2 = nullptr; }
         launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
         return;
     }
@@ -1258,6 +1260,7 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
     p.A = cur(m).ws.O; p.lda = A; p.W = w.wo; p.bias = w.bo; p.C = out; p.ldc = D; p.N = D; p.Kc = A;
     p.resid = resid; p.ldr = D;
     if (x3) { use_x3(p, w.wox); p.C2 = out_split; }
+    if (x3 && split_only && out_split) { p.C = out_split; p.c_split = 1; p.C2 = nullptr; }
     launch_gemm(m, p, false, false, want_out_stats ? STATS_PARTIALS : STATS_NONE);
 }
 
@@ -1408,7 +1411,9 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         if (m->debug_stop_after == 100 + n) return HD_OK;        // (tests: right behind the first attention of block n)
         // at = at + A2(LN1(at))      (statistics of `at` come from the out-projection's epilogue)
         if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
-        attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true, ax3, ws.ATX, ws.ATX);
+        // (split route: FF1 is the only reader of this sum -- the block's last residual comes from the block INPUT -- and reads it in split
+        //  form, so the fp32 rows are not written: 229 MB per launch at 256 antibodies)
+        attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true, ax3, ws.ATX, ws.ATX, /*split_only=*/ax3);
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;

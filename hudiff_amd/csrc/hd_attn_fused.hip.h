@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
     const int foff0 = (lane & 31) * 64 + (((0 + fg) ^ fsw) << 4), foff1 = (lane & 31) * 64 + (((2 + fg) ^ fsw) << 4);
     const int aoff0 = (lane & 31) * 128 + (((0 + fg) ^ asw) << 4), aoff1 = (lane & 31) * 128 + (((4 + fg) ^ asw) << 4);      // (X16: hi chunk 4 ks + g)
     // The K loop, software-pipelined by hand.  A k tile is four steps -- (k step 0 | 1) x (row tiles 0-2 | 3-4) -- and the fragments of
-    // step s + 1 are requested from LDS BEFORE the MFMAs of step s are issued, so that only the first request of a tile (right behind
-    // the barrier that published the stage) waits for the LDS; the batches of 3 + 2 tiles keep at most 56 fragment registers live beside
+    // step s + 1 are requested from LDS BEFORE the MFMAs of step s are issued (across the tile's closing barrier too: wave_program);
+    // the batches of 3 + 2 tiles keep at most 56 fragment registers live beside
     // the 80 accumulators (three waves per SIMD: 168 registers).  hipcc left to itself read every fragment right in front of its MFMA
     // (s_waitcnt lgkmcnt between them) once the whole-tile form had spilled the accumulators.
     // Per step: the two cross terms first, the leading term last (gemm_x3_k's order), independent accumulators inside a term.
@@ -210,40 +210,80 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
         row_rstd();
         __builtin_amdgcn_s_waitcnt(WAIT_ALL);
         lds_barrier();
-        for (int kt = 0, st = 0; kt < nkt; ++kt, st ^= 1) {
-            const char* At = qas + st * STAGE + rg * TM * 32 * 128;
-            const char* Wt = qas + st * STAGE + A_BYTES + ct * 32 * 64;
-            f16x8 a0h[3], a0l[3], b0h[2], b0l[2], a1h[3], a1l[3], b1h[2], b1l[2];
-            if (p.abl & 1) {                           // probe: no MFMAs (and no fragment reads)
+#ifdef HD_QA_STAMPS
+        uint32_t ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // probe build: shader-clock stamps of k tiles 10 and 11 (start, [10: own DMA issued,] last MFMA issued, DMA landed) + start of tile 12
+#endif
+        // The loop carries two things over a tile's closing barrier: the tile's LAST MFMA batch (row tiles 3-4 of k step 1; its fragments are in
+        // registers, the stage is free) and -- requested right behind the barrier, in front of that batch -- the next tile's first fragments.
+        // The matrix pipe then has eighteen MFMAs per SIMD to run while the first LDS reads of the new tile are under way, instead of
+        // draining at every barrier and idling for a read round trip behind it (tile stamps, NOTES.md D: ~600 of a tile's ~3 900 clocks).
+        // Order of the products inside every accumulator: unchanged.
+        if (p.abl & 1) {                               // probe: no MFMAs (and no fragment reads)
+            for (int kt = 0, st = 0; kt < nkt; ++kt, st ^= 1) {
                 if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
-            } else {
-            const f16x8 w0h = *reinterpret_cast<const f16x8*>(Wt + foff0), w0l = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + foff0);
-            load_x(At, aoff0, c0, c3, a0h, a0l);
-            // the other stage was read in tile kt - 1 and every wave is past that tile's barrier: its DMA goes out behind this tile's
-            // first fragment requests (they are what the first MFMAs wait for)
-            // (issuing the DMA in two or three portions over the MFMA steps instead changes nothing: 716 / 715 / 720 us per launch, NOTES.md D)
-            if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
-            load_x(At, aoff0, c3, c2, b0h, b0l);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(sw_c, c0, c3, a0h, a0l, w0h, w0l);
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 w1h = *reinterpret_cast<const f16x8*>(Wt + foff1), w1l = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + foff1);
-            load_x(At, aoff1, c0, c3, a1h, a1l);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(sw_c, c3, c2, b0h, b0l, w0h, w0l);
-            __builtin_amdgcn_sched_barrier(0);
-
-            load_x(At, aoff1, c3, c2, b1h, b1l);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(sw_c, c0, c3, a1h, a1l, w1h, w1l);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(sw_c, c3, c2, b1h, b1l, w1h, w1l);
+                __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+                lds_barrier();
             }
-            __builtin_amdgcn_s_waitcnt(WAIT_ALL);      // tile kt + 1 has landed ...
-            lds_barrier();                             // ... everybody's part of it; everybody is done reading tile kt
+        } else {
+            f16x8 a0h[3], a0l[3], b0h[2], b0l[2], a1h[3], a1l[3], b1h[2], b1l[2], w0h, w0l, w1h, w1l;
+            {
+                const char* At = qas + rg * TM * 32 * 128;
+                const char* Wt = qas + A_BYTES + ct * 32 * 64;
+                w0h = *reinterpret_cast<const f16x8*>(Wt + foff0); w0l = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + foff0);
+                load_x(At, aoff0, c0, c3, a0h, a0l);
+            }
+            for (int kt = 0, st = 0; kt < nkt; ++kt, st ^= 1) {
+#ifdef HD_QA_STAMPS
+                if (kt == 10) ts[0] = (uint32_t)__builtin_readcyclecounter();
+                if (kt == 11) ts[4] = (uint32_t)__builtin_readcyclecounter();
+                if (kt == 12) ts[7] = (uint32_t)__builtin_readcyclecounter();
+#endif
+                const char* At = qas + st * STAGE + rg * TM * 32 * 128;
+                const char* Wt = qas + st * STAGE + A_BYTES + ct * 32 * 64;
+                // the other stage was read in tile kt - 1 and every wave is past that tile's barrier
+                if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
+#ifdef HD_QA_STAMPS
+                if (kt == 10) ts[1] = (uint32_t)__builtin_readcyclecounter();
+#endif
+                load_x(At, aoff0, c3, c2, b0h, b0l);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(sw_c, c0, c3, a0h, a0l, w0h, w0l);
+                __builtin_amdgcn_sched_barrier(0);
+                w1h = *reinterpret_cast<const f16x8*>(Wt + foff1); w1l = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + foff1);
+                load_x(At, aoff1, c0, c3, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(sw_c, c3, c2, b0h, b0l, w0h, w0l);
+                __builtin_amdgcn_sched_barrier(0);
+                load_x(At, aoff1, c3, c2, b1h, b1l);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(sw_c, c0, c3, a1h, a1l, w1h, w1l);
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef HD_QA_STAMPS
+                if (kt == 10) ts[2] = (uint32_t)__builtin_readcyclecounter();
+                if (kt == 11) ts[5] = (uint32_t)__builtin_readcyclecounter();
+#endif
+                __builtin_amdgcn_s_waitcnt(WAIT_ALL);  // tile kt + 1 has landed ...
+#ifdef HD_QA_STAMPS
+                if (kt == 10) ts[3] = (uint32_t)__builtin_readcyclecounter();
+                if (kt == 11) ts[6] = (uint32_t)__builtin_readcyclecounter();
+#endif
+                lds_barrier();                         // ... everybody's part of it; everybody has READ all of tile kt (the last fragments are in registers)
+                {                                      // (behind the last tile: reads of the other stage nobody uses -- no branch in the loop body)
+                    const char* An = qas + (st ^ 1) * STAGE + rg * TM * 32 * 128;
+                    const char* Wn = qas + (st ^ 1) * STAGE + A_BYTES + ct * 32 * 64;
+                    w0h = *reinterpret_cast<const f16x8*>(Wn + foff0); w0l = *reinterpret_cast<const f16x8*>(Wn + W_BYTES / 2 + foff0);
+                    load_x(An, aoff0, c0, c3, a0h, a0l);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(sw_c, c3, c2, b1h, b1l, w1h, w1l);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-
         stamp(0);                                      // K loop done
+#ifdef HD_QA_STAMPS
+        if (h0 == 0 && lane == 0)
+            for (int k = 1; k < 8; ++k) p.QKV[(long)(rA0 + p.sg.off[0] + 1) * p.ldq + 2 * p.att + wave * 8 + k] = (float)(ts[k] - ts[0]);
+#endif
         // ---- hand-over, step 1: finish the values in place (scale, rstd of a folded LayerNorm, bias); Q rows go out -----------
         if constexpr (PART == 2) {                     // V: rows x d -- a lane holds rows 8 j + 4 khalf + (0 .. 3) of each tile: one 16-byte read of their rstd
             const float bv = bias_s[ct * 32 + l31];

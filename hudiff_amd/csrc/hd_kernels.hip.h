@@ -1280,6 +1280,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         else if (!(need & ~EPI_FOLD)) HD_EPI(EPI_FOLD);
         else if (!(need & ~(EPI_FOLD | EPI_ACT | EPI_CSPLIT))) HD_EPI(EPI_FOLD | EPI_ACT | EPI_CSPLIT);
         else if (!(need & ~(EPI_RESID | EPI_PART | EPI_C2))) HD_EPI(EPI_RESID | EPI_PART | EPI_C2);
+        else if (!(need & ~(EPI_RESID | EPI_PART | EPI_CSPLIT))) HD_EPI(EPI_RESID | EPI_PART | EPI_CSPLIT);
         else HD_EPI(EPI_ALL);
     }
 #undef HD_EPI
