@@ -1123,20 +1123,20 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // 16 rows x 64 B of one plane, copied linearly.  Rows past the segment end and conv padding get an offset the descriptor's
     // range check rejects: the DMA writes zeros.
     constexpr uint32_t BUF_OOB = 0x80000000u;
+    // a_base: byte offset of the piece's row (no shift) + swizzled chunk; a_pos: slot of that row in its chain (conv), a value no shift
+    // brings into [0, Lc) for a row past the segment end
     int a_pos[A_PIECES];
-    long a_row[A_PIECES];
-    bool a_ok[A_PIECES];
-    uint32_t a_in[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
+    uint32_t a_base[A_PIECES], a_vo[A_PIECES], w_vo[W_PIECES];
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
         const int piece = NW * i + wave;                                 // rows 8 piece ..
         const int r = 8 * piece + (lane >> 3);
         const int lrow = m0 + r;
-        a_ok[i] = lrow < seg_rows;
-        a_pos[i] = CONV ? (lrow % Lc) : 0;
-        a_row[i] = a_ok[i] ? (long)rbase + lrow : 0;
-        a_in[i] = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);      // swizzled chunk of the 128-byte group
-        a_vo[i] = a_ok[i] ? (uint32_t)(a_row[i] * p.lda * 4) + a_in[i] : BUF_OOB;
+        const bool ok = lrow < seg_rows;
+        a_pos[i] = !ok ? -(1 << 24) : CONV ? (lrow % Lc) : 0;
+        const uint32_t a_in = (uint32_t)((((lane & 7) ^ ((r >> 1) & 7))) << 4);      // swizzled chunk of the 128-byte group
+        a_base[i] = ok ? (uint32_t)(((long)rbase + lrow) * p.lda * 4) + a_in : 0u;
+        a_vo[i] = ok ? a_base[i] : BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
@@ -1148,26 +1148,27 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wx), 0, (BN / X3_BN) * nkt * X3_TILE_BYTES, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_vp;
+    // (Round 5, measured and not kept -- NOTES.md D: the taps as the INNER loop index and an XCD walking through neighbouring M tiles cut what
+    //  the tap GEMM pulls through the fabric from 7.7 x to 2.3 x its A operand (L2 hit rate 0.80 -> 0.92) and made the launch 10 % slower.)
+    int d_tap = 0, d_kk = 0;                           // (tap, k tile inside the tap) of the NEXT dma() call: calls come in loop order
     auto dma = [&](int kt, int st) {
-        const int tap = CONV ? kt / nkt_tap : 0;
-        const int kk0 = (CONV ? kt - tap * nkt_tap : kt) * BK;
-        if (CONV && kk0 == 0) {                        // first k tile of a tap: row shift + zero padding at the chain ends
-            const int shift = (tap - half) * p.dil;
+        if (CONV && d_kk == 0) {                       // first k tile of a tap: row shift + zero padding at the chain ends
+            const int shift = (d_tap - half) * p.dil;
+            const uint32_t soff = (uint32_t)(shift * p.lda * 4);
 #pragma unroll
-            for (int i = 0; i < A_PIECES; ++i) {
-                const int sp = a_pos[i] + shift;
-                const bool v = a_ok[i] && sp >= 0 && sp < Lc;
-                a_vo[i] = v ? (uint32_t)((a_row[i] + shift) * p.lda * 4) + a_in[i] : BUF_OOB;
-            }
+            for (int i = 0; i < A_PIECES; ++i)
+                a_vo[i] = (unsigned)(a_pos[i] + shift) < (unsigned)Lc ? a_base[i] + soff : BUF_OOB;
         }
         char* dst = St + st * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], kk0 * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], (CONV ? d_kk : kt) * BK * 4, 0, 0);
+        const int wt = CONV ? d_tap * nkt_tap + d_kk : kt;        // weight images are stored tap-major
 #pragma unroll
         for (int i = 0; i < W_PIECES; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(dst + A_BYTES + (NW * i + wave) * 1024), 16, (int)w_vo[i],
-                                                     kt * X3_TILE_BYTES, 0, 0);
+                                                     wt * X3_TILE_BYTES, 0, 0);
+        if (CONV && ++d_kk == nkt_tap) { d_kk = 0; ++d_tap; }
     };
 
     f32x16 acc[TM][TN];
