@@ -329,12 +329,48 @@ __host__ __device__ __forceinline__ int epi_needs(const GemmP& p) {
            (p.extra ? EPI_EXTRA : 0) | (p.part ? EPI_PART : 0) | (p.c_split ? EPI_CSPLIT : 0) | (p.C2 ? EPI_C2 : 0) |
            (p.ln_sync ? EPI_LNSYNC : 0);
 }
+// What a small tile's epilogue would open with, requested BEFORE the K loop instead (gemm_x3_k, BM = 32): bias, the residual values of
+// the wave's one 32-row pass, and gamma / beta of an ln_sync second pass.  A launch of a handful of sequences is a chain of memory round
+// trips of ~1 us (NOTES.md D); these then travel with the first operand tiles.  (For the 128-row tiles the same was measured and dropped:
+// see below; gemm_x3_k says why the 64-row tiles do not take it.)
+template <int NIT>
+struct EpiPre { f32x4 bv, gv, bv2, rres[NIT]; };
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epi_prefetch(const GemmP& p, EpiPre<32 / (64 / (BN / WN / 4))>& pre, int seg, int seg_rows, int rbase, int m0, int n0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, LPR = WTN / 4, RPI = 64 / LPR;
+    static_assert(WTM == 32, "one 32-row pass per wave");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int e_c4 = (lane % LPR) * 4, e_r = lane / LPR;
+    const int col = n0 + wn * WTN + e_c4;
+    const bool col_ok = col < p.N;
+    const int colc = col_ok ? col : 0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    pre.bv = z; pre.gv = z; pre.bv2 = z;
+    if (p.bias && col_ok) pre.bv = *reinterpret_cast<const f32x4*>(p.bias + seg * p.n_stride + col);
+    if (p.ln_sync && col_ok) {
+        pre.gv = *reinterpret_cast<const f32x4*>(p.gamma2 + seg * p.k2_stride + col);
+        pre.bv2 = *reinterpret_cast<const f32x4*>(p.beta2 + seg * p.k2_stride + col);
+    }
+    const int wrow0 = m0 + wm * WTM;
+    const uint32_t r_vo = (uint32_t)((e_r * p.ldr + colc) * 4);
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+        pre.rres[it] = z;
+        if (p.resid) {
+            const int g0 = wrow0 + it * RPI;
+            const bool ok = g0 + e_r < seg_rows && col_ok;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + (long)(rbase + g0) * p.ldr, 0, 0x7FFFFFFF, 0x00020000);
+            pre.rres[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : 0x80000000u), 0, 0));
+        }
+    }
+}
 // (Requesting a block's residual values BEFORE its K loop -- 64 registers in the 128 x 128 instantiation, so that their HBM round trips
 //  travel under the loop instead of opening every 32-row pass -- was built and measured in round 5: 99.4 vs 99.9 sequences/s, removed.)
-template <int BM, int BN, int WM, int WN, int F = EPI_ALL>
+template <int BM, int BN, int WM, int WN, int F = EPI_ALL, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const float2* rowst, int seg, int seg_rows, int rbase, int Lc, int m0, int n0,
-                                              int by) {
+                                              int by, const EpiPre<32 / (64 / (BN / WN / 4))>* pre = nullptr) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int ES = WTN + 4;
@@ -369,7 +405,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
     const bool col_ok = col < N;
     const int colc = col_ok ? col : 0;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    if constexpr (PRE) bv = pre->bv;
+    else if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
     // Global accesses of the epilogue: descriptor whose base is the first row of the current 4-row group (moved with
     // scalar adds) + a lane offset fixed for the whole block; a lane switched off by BUF_OFF reads 0 / stores nothing
     // (offset beyond num_records), so there is no per-row 64-bit address arithmetic on the vector ALU.
@@ -417,6 +454,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
         // overwrite, so hoisting the loads above the stores is safe even when resid aliases C); they travel
         // while the accumulators are transposed through LDS instead of serialising load -> store per row
         f32x4 rres[32 / RPI];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) rres[it] = pre->rres[it];
+        } else
         if (has_resid) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
@@ -624,7 +665,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const float* __restrict__ g2 = p.gamma2 + seg * p.k2_stride;
             const float* __restrict__ b2 = p.beta2 + seg * p.k2_stride;
             f32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv2 = {0.f, 0.f, 0.f, 0.f};
-            if (col_ok) { gv = *reinterpret_cast<const f32x4*>(g2 + col); bv2 = *reinterpret_cast<const f32x4*>(b2 + col); }
+            if constexpr (PRE) { gv = pre->gv; bv2 = pre->bv2; }
+            else if (col_ok) { gv = *reinterpret_cast<const f32x4*>(g2 + col); bv2 = *reinterpret_cast<const f32x4*>(b2 + col); }
             float smax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -656,7 +698,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
 // (mean, rstd) of an A row: either ready-made or merged from the producing GEMM's (mean, M2) slice partials (Chan et al.)
 __device__ __forceinline__ float2 merge_row_stat(const float2* __restrict__ spart, int spw, long spart_rows, int Kc, long grow) {
     const int P = (Kc + spw - 1) / spw;
-    constexpr int PM = 16;
+    constexpr int PM = 24;                             // (768 columns in 32-wide slices -- the 32 x 128 tiles of small launches -- are 24)
     if (P <= PM) {
         // all slices of the row in flight at once, both passes from registers: ONE round trip (the partials were written by the
         // previous launch) instead of two; the same additions in the same order as the loops below
@@ -1110,14 +1152,6 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // weight images are packed per 128-column tile: this block's BN / 128 tiles are nkt * 16 KiB apart
     const uint16_t* __restrict__ Wx = p.Wx + (long)seg * p.wx_stride + (long)by * (BN / X3_BN) * nkt * X3_TILE_HALFS;
 
-    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
-        float2* rowst = reinterpret_cast<float2*>(smem + WORK_FLOATS);
-        for (int r = tid; r < BM; r += NT) {
-            const int lrow = m0 + r;
-            rowst[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
-        }
-        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
-    }
     // A pieces of 1 KiB = 8 rows x 128 B: lane l lands at piece base + 16 l = row l >> 3, slot l & 7, and fetches chunk
     // slot ^ swizzle(row) of the row's 128-byte (hi | lo) group of this k tile -- one full cache line per row.  W pieces of 1 KiB =
     // 16 rows x 64 B of one plane, copied linearly.  Rows past the segment end and conv padding get an offset the descriptor's
@@ -1232,9 +1266,24 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
     constexpr int WAIT_STEADY = (KEEP & 0xF) | ((KEEP >> 4) << 14) | 0x0F70, WAIT_ALL = 0x0F70;
     const bool does_dma = LW == 0 || loader, does_mma = LW == 0 || !loader;
+    // 32-row tiles (launches of a handful of sequences): the epilogue's opening loads go out in front of the K loop (EpiPre).  Not the
+    // 64-row tiles: the 44 registers this holds across the loop would take them from three blocks per CU to two.
+    constexpr bool PRE = BM == 32;
+    EpiPre<32 / (64 / (WTN / 4))> pre;
+    if constexpr (PRE) { if (does_mma) epi_prefetch<BM, BN, WM, WN>(p, pre, seg, seg_rows, rbase, m0, n0); }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nkt && does_dma) dma(t, t);
+    if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
+        // (requested behind the first tiles' DMA, so that this round trip -- one: merge_row_stat -- travels with theirs; a small launch
+        //  is a chain of such round trips)
+        float2* rowst_w = reinterpret_cast<float2*>(smem + WORK_FLOATS);
+        for (int r = tid; r < BM; r += NT) {
+            const int lrow = m0 + r;
+            rowst_w[r] = gemm_row_stat(p, lrow < seg_rows ? (long)rbase + lrow : (long)rbase);
+        }
+        // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
+    }
     if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
     lds_barrier();
     int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
@@ -1268,7 +1317,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
     const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
     const int need = p.x3_abl & 64 ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);
-#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by)
+#define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3, PRE>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by, &pre)
     if (need & EPI_LNSYNC) {
         // (only the 4-wave 128 x 128 instantiation is ever launched with ln_sync; the others keep the code out)
         if constexpr (NW == 4 && EPISET != 1) {
