@@ -1185,7 +1185,9 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // (Round 5, measured and not kept -- NOTES.md D: the taps as the INNER loop index and an XCD walking through neighbouring M tiles cut what
     //  the tap GEMM pulls through the fabric from 7.7 x to 2.3 x its A operand (L2 hit rate 0.80 -> 0.92) and made the launch 10 % slower.)
     int d_tap = 0, d_kk = 0;                           // (tap, k tile inside the tap) of the NEXT dma() call: calls come in loop order
-    auto dma = [&](int kt, int st) {
+    // dma() = dma_a() + dma_w(): the A pieces, then the W pieces of the next tile in loop order (the pipelined loop below issues the two
+    // halves in the issue slots between dependent MFMA groups)
+    auto dma_a = [&](int kt, int st) {
         if (CONV && d_kk == 0) {                       // first k tile of a tap: row shift + zero padding at the chain ends
             const int shift = (d_tap - half) * p.dil;
             const uint32_t soff = (uint32_t)(shift * p.lda * 4);
@@ -1197,6 +1199,9 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_vp)(dst + (NW * i + wave) * 1024), 16, (int)a_vo[i], (CONV ? d_kk : kt) * BK * 4, 0, 0);
+    };
+    auto dma_w = [&](int kt, int st) {
+        char* dst = St + st * STAGE_BYTES;
         const int wt = CONV ? d_tap * nkt_tap + d_kk : kt;        // weight images are stored tap-major
 #pragma unroll
         for (int i = 0; i < W_PIECES; ++i)
@@ -1204,6 +1209,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
                                                      wt * X3_TILE_BYTES, 0, 0);
         if (CONV && ++d_kk == nkt_tap) { d_kk = 0; ++d_tap; }
     };
+    auto dma = [&](int kt, int st) { dma_a(kt, st); dma_w(kt, st); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1271,9 +1277,18 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     constexpr bool PRE = BM == 32;
     EpiPre<32 / (64 / (WTN / 4))> pre;
     if constexpr (PRE) { if (does_mma) epi_prefetch<BM, BN, WM, WN>(p, pre, seg, seg_rows, rbase, m0, n0); }
+    // PIPE: the K loop of the 4-wave, 64- / 128-row tiles, software-pipelined by hand (round 5; same products in the same order).  The
+    // compiler's loop (below; kept for the small tiles, the loader-wave form and the probes) reads a k step's fragments right in front of
+    // its MFMAs and drains the matrix pipe at every barrier: isolated, its MFMA-only time was 1.35 x the MFMA floor.  Here the fragments
+    // of k step s + 1 are requested BEFORE the MFMAs of step s are issued, a tile's second MFMA batch is carried over the tile's closing
+    // barrier (its fragments are in registers, so the stage is free), and the next tile's DMA instructions go out in the issue slots
+    // between the three dependent MFMA groups of that batch -- what qkv_attn_x3_k does (hd_attn_fused.hip.h).
+    constexpr bool PIPE = LW == 0 && NW == 4 && BM >= 64;
+    const bool pipe = PIPE && abl_mode == 0;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nkt && does_dma) dma(t, t);
+    if (pipe && NS - 1 < nkt) dma(NS - 1, NS - 1);     // (the pipelined loop keeps NS - 1 tiles in flight BEHIND the one it multiplies)
     if (p.ln_fold) {                                   // folded LayerNorm: the epilogue needs rstd of every row of the tile
         // (requested behind the first tiles' DMA, so that this round trip -- one: merge_row_stat -- travels with theirs; a small launch
         //  is a chain of such round trips)
@@ -1284,6 +1299,63 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         }
         // visible to every wave after the barriers of the K loop (each block runs at least one k tile)
     }
+    if constexpr (PIPE) {
+        if (pipe) {
+            constexpr int KEEP0 = (NS - 1) * PER_TILE;
+            static_assert(KEEP0 < 64, "vmcnt is a 6-bit counter");
+            constexpr int WAIT_FIRST = (KEEP0 & 0xF) | ((KEEP0 >> 4) << 14) | 0x0F70;
+            if (NS <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_FIRST); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
+            lds_barrier();
+            f16x8 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+            auto frag = [&](int st, int o, int oa, f16x8* ah, f16x8* al, f16x8* bh, f16x8* bl) {
+                const char* At = St + st * STAGE_BYTES + wm * WTM * 128;
+                const char* Wt = St + st * STAGE_BYTES + A_BYTES + wn * WTN * 64;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(At + oa + 32 * 128 * i);
+                    al[i] = *reinterpret_cast<const f16x8*>(At + (oa ^ 32) + 32 * 128 * i);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(Wt + o + 32 * 64 * j);
+                    bl[j] = *reinterpret_cast<const f16x8*>(Wt + W_BYTES / 2 + o + 32 * 64 * j);
+                }
+            };
+            // the three dependent groups of a k step: cross terms first, the leading term last (mma()'s order)
+            auto g1 = [&](const f16x8* al, const f16x8* bh) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            };
+            frag(0, foff0, aoff0, ah0, al0, bh0, bl0);
+            int st = 0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int st_next = st + 1 == NS ? 0 : st + 1;
+                frag(st, foff1, aoff1, ah1, al1, bh1, bl1);
+                __builtin_amdgcn_sched_barrier(0);
+                g1(al0, bh0); g1(ah0, bl0); g1(ah0, bh0);
+                __builtin_amdgcn_sched_barrier(0);
+                // tile kt + 1 has landed (tiles kt + 2 .. kt + NS - 1 may stay in flight) ...
+                if (kt + NS - 1 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+                lds_barrier();                         // ... everybody's part of it; everybody has READ all of tile kt (k step 1 is in registers)
+                frag(st_next, foff0, aoff0, ah0, al0, bh0, bl0);      // (behind the last tile: a read nobody uses -- no branch in the loop body)
+                __builtin_amdgcn_sched_barrier(0);
+                g1(al1, bh1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + NS < nkt) dma_a(kt + NS, st);                 // stage st is free: tile kt + NS
+                __builtin_amdgcn_sched_barrier(0);
+                g1(ah1, bl1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + NS < nkt) dma_w(kt + NS, st);
+                __builtin_amdgcn_sched_barrier(0);
+                g1(ah1, bh1);
+                __builtin_amdgcn_sched_barrier(0);
+                st = st_next;
+            }
+        }
+    }
+    if (!pipe) {
     if (NS - 1 <= nkt) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // tile 0 has landed
     lds_barrier();
     int st = 0, st_in = NS - 1;                        // stage of tile kt / stage the next DMA fills (= the one tile kt-1 used)
@@ -1297,6 +1369,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         lds_barrier();                                 // ... everybody's part of it; everybody is done reading tile kt
         st_in = st;
         st = st + 1 == NS ? 0 : st + 1;
+    }
     }
     // The loader waves end here, ahead of the epilogue's barriers (ln_sync meeting).  gfx9-family hardware (gfx950 included: ISA
     // "s_barrier": a wave that has terminated no longer takes part) completes a barrier when every wave of the workgroup that has
