@@ -197,16 +197,22 @@ def cpu_baseline(kind, cfg, sd, mode, rows, steps, mean_T, impl="auto", data="au
     if threads is not None:
         # many-core hosts oversubscribe these matrix sizes (256 logical CPUs: 0.035 sequences/s on 128 threads, 0.145 on 16):
         # one step per candidate thread count -- up to ALL physical cores -- the timed sample runs on the fastest
+        # (ascending, and the sweep stops once a count is 1.5 x slower than the best so far: on the 128-core box the 64- and 128-thread
+        #  probes alone took four minutes of a run whose timed CPU sample is ten seconds)
         import torch
-        best = None
+        best, tried = None, []
         for n in sorted({8, 16, 32, min(64, phys), phys}):
             torch.set_num_threads(n)
             dtn = run(rows, 1)
+            tried.append(n)
             if best is None or dtn < best[0]:
                 best = (dtn, n)
+            elif dtn > 1.5 * best[0]:
+                break
         threads = best[1]
         torch.set_num_threads(threads)
-        name += f" (fastest of 8/16/32/64/{phys} threads)"
+        name += f" (fastest of {'/'.join(map(str, tried))} threads; more threads were slower by more than 1.5 x)" if tried[-1] != phys else \
+                f" (fastest of {'/'.join(map(str, tried))} threads)"
     dt_b = run(rows, steps)
     steps1 = max(2, steps // 2)
     run(1, 1)
