@@ -465,7 +465,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 const bool ok = g0 + e_r < seg_rows && col_ok;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(p.resid) + (long)(rbase + g0) * p.ldr, 0, BUF_MAX, 0x00020000);
-                rres[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : BUF_OFF), 0, 0));
+                // (split route: the residual rows are read ONCE per launch -- 229 MB at 256 antibodies -- so they are asked for non-temporally and
+                //  leave the XCD's L2 to the operand tiles its blocks share)
+                rres[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? r_vo : BUF_OFF), 0, (F & EPI_X3) ? 2 : 0));
             }
         }
 #pragma unroll
