@@ -1205,7 +1205,9 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
                fuse10 = m->L > 16 * 9 && m->L <= 16 * 10 && m->cfg.nhead % 2 == 0 && lds_fill_ok(QaGeom<10, 2>::smem(m->L), QA_THREADS);
     const long fused_blocks = (long)sg.B * (m->cfg.nhead / (fuse19 ? 1 : 2)) * (m->in_session ? m->nlanes : 1);      // workgroups of all lanes' launches
     if (x3 && x_split && w.wqkvx.w && m->opt[HD_OPT_FUSED_ATTN] && fused_blocks >= m->opt[HD_OPT_FUSED_ATTN_MIN_GRID] && m->opt[HD_OPT_SPLIT_ATTN] && (fuse19 || fuse10) && D % X3_BK == 0 && A % X3_BN == 0 &&
-        (long)sg.rows() * 3 * A * 4 < (1L << 31) && (long)sg.rows() * D * 4 < (1L << 31)) {
+        (long)sg.rows() * 3 * A * 4 < (1L << 31) && (long)sg.rows() * D * 4 < (1L << 31) &&
+        // (the Q fragments of head h, query tile qt travel through the Q | K thirds of row h KT + qt of the sequence's first-segment rows: 4 KiB each)
+        m->cfg.nhead * (fuse19 ? 19 : 10) <= sg.len[0] && 2 * A * 4 >= 4096) {
         QkvAttnP q{};
         q.X = x_split; q.ldx = D; q.x_bytes = (uint32_t)((long)sg.rows() * D * 4);
         q.Wx = w.wqkvx.w; q.acc_scale = w.wqkvx.acc_scale; q.bias = w.bqkv;

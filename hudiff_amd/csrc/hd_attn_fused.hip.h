@@ -13,8 +13,8 @@
 //                   multiplied as W^T X^T (operands swapped) so that a lane ends up with four consecutive head dimensions of ONE key
 //                   -- the RoPE pairs and an 8-byte piece of the K plane row -- while Q and V come out rows x d, which is what the
 //                   fp32 Q rows and the key-major V^T planes want.
-//   2. hand-over    accumulators -> [rstd of a folded LayerNorm] -> + bias -> Q: fp32 rows to global (the workgroup reads them back
-//                   past the L1, 74 KB per head); K: rotated, split, into the K planes; V: split, into the permuted V^T planes -- the
+//   2. hand-over    accumulators -> [rstd of a folded LayerNorm] -> + bias -> Q: rotated, scaled, split, to global as the core's MFMA fragments
+//                   (the workgroup reads them back past the L1, 76 KB per head); K: rotated, split, into the K planes; V: split, into the permuted V^T planes -- the
 //                   very LDS images attn_x3_k stages (AxGeom), laid over the operand stages once every wave has left the K loop.
 //   3. attention    attn_x3_tiles (hd_kernels.hip.h), unchanged: S^T = K Q^T, fp32 softmax, O^T = V^T P^T, O rows out in X16 form.
 // Antibody model (L = 291): one head per workgroup, 304 x 192 tile (stages 2 x 64 KB, planes 156 KB); nanobody model (L = 152): two
@@ -309,20 +309,52 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
                 for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * sc * rs_k + bv[r >> 2][r & 3];
             }
         }
-        if constexpr (PART == 0) {                     // Q: fp32 rows [row, hcol + d], 16 bytes per lane; read back by attn_x3_tiles below (same workgroup)
+        if constexpr (PART == 0) {
+            // Q goes to the attention core through global memory (the planes fill the LDS), READY TO MULTIPLY (round 5, core stamps: the fp32
+            // rows this used to store cost every query tile twelve scattered loads -- Q rows at a 6 KB stride, RoPE table rows -- before its
+            // first MFMA: 4 200 .. 13 700 clocks per tile, the longest phase of the core).  Here the Q waves rotate, scale (log2(e) / 8) and
+            // split their rows, and store them as the B-operand fragments of S^T = K Q^T in the order the core's lanes read them: the 4 KiB
+            // block of query tile qt = [k step 0 hi | k step 0 lo | k step 1 hi | k step 1 lo] x [lane qi + 16 g] x 16 bytes, so that a tile
+            // is four fully coalesced 1 KiB loads.  Block (head h, tile qt) lies in the Q | K thirds (4 KiB) of row h KT + qt of the
+            // sequence's first-segment rows (the host checks nhead KT <= rows of the segment; the V third stays free for the probes' stamps).
             const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(p.QKV, 0, 0x7fffffff, 0x00020000);
-            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            constexpr float QS = 0.125f * 1.44269504088896340736f;
+            float vmaxq = 0.f;                             // range guard of the Q split (the core used to raise it)
+            f32x4 cs[2][4];
+            auto load_cs = [&](int i, f32x4 (&dst)[4]) {
+                const int key = 32 * (rg * TM + i) + l31;
+                const int kc = key < L ? key : L - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dst[j] = *reinterpret_cast<const f32x4*>(p.rope_cs + (kc * 32 + ((32 * half + 8 * j + 4 * khalf) >> 1)) * 2);
+            };
+            load_cs(0, cs[0]);
+            const uint32_t blk0 = (uint32_t)(rA0 + p.sg.off[0] + (h0 + hh) * KT) * (uint32_t)p.ldq * 4u;      // block of (this head, tile 0)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = 32 * (rg * TM + i) + l31;
-                const int grow = m + (m >= roff1 ? rA1 : rA0);
-                const uint32_t rowb = m < L ? ((uint32_t)grow * (uint32_t)p.ldq + (uint32_t)(hcol + 32 * half + 4 * khalf)) * 4u : BUF_OOB;
+                if (i + 1 < TM) load_cs(i + 1, cs[(i + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t tb = m < 16 * KT ? blk0 + (uint32_t)(m >> 4) * (uint32_t)p.ldq * 4u + (uint32_t)(2 * half) * 1024u + (uint32_t)(m & 15) * 16u + (uint32_t)khalf * 8u
+                                                : BUF_OOB;                      // (32 RT rows are multiplied, 16 KT tiles exist)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 qv = {acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, qv), q_rs, (int)(rowb + (uint32_t)(8 * j) * 4u), 0, 0);
+                    const f32x4 c4 = cs[i & 1][j];
+                    const float q0 = acc[i][4 * j], q1 = acc[i][4 * j + 1], q2 = acc[i][4 * j + 2], q3 = acc[i][4 * j + 3];
+                    f32x4 r;
+                    r[0] = (q0 * c4[0] - q1 * c4[1]) * QS; r[1] = (q0 * c4[1] + q1 * c4[0]) * QS;
+                    r[2] = (q2 * c4[2] - q3 * c4[3]) * QS; r[3] = (q2 * c4[3] + q3 * c4[2]) * QS;
+                    f16x4 hv, lv;
+                    split4(r, hv, lv);
+                    if ((HD_GUARD_MASK & 16) && m < L) vmaxq = absmax4(vmaxq, r);
+                    const uint32_t o = tb == BUF_OOB ? BUF_OOB : tb + (uint32_t)(16 * j) * 16u;       // lane qi + 16 g of the core, g = j
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hv), q_rs, (int)o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, lv), q_rs, (int)(o == BUF_OOB ? BUF_OOB : o + 1024u), 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            raise_range_flag(p.rs, vmaxq);
         }
         stamp(1);                                      // step 1 done
         lds_barrier();                                 // every wave has left the K loop and read its rstd: the planes may overwrite both
@@ -414,8 +446,14 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
 #pragma unroll
     for (int hx = 0; hx < NH; ++hx) {
         const char* pl = qas + hx * Q::planes(L);
+#ifdef HD_QA_STAMPS
+        float* cstamps = (h0 == 0 && hx == 0) ? p.QKV + (long)(rA0 + p.sg.off[0] + 2) * p.ldq + 2 * p.att : nullptr;      // third row of the sequence, V third
+#else
+        float* cstamps = nullptr;
+#endif
         attn_x3_tiles<KT, QA_THREADS, true>(pl, pl + krows * 128, pl + 2 * krows * 128, pl + 2 * krows * 128 + G::VPLANE, p.QKV, p.ldq,
-                                            (h0 + hx) * ATT_HD, p.rope_cos, p.rope_sin, o_rs, p.ldo, b, h0 + hx, p.sg, 1, p.rs, lane, wave);
+                                            (int)((uint32_t)(rA0 + p.sg.off[0] + (h0 + hx) * KT) * (uint32_t)p.ldq * 4u),      // (QL2: byte offset of the head's Q fragment blocks)
+                                            p.rope_cos, p.rope_sin, o_rs, p.ldo, b, h0 + hx, p.sg, 1, p.rs, lane, wave, cstamps);
     }
     stamp(5);                                          // attention done
 }

@@ -1907,14 +1907,22 @@ constexpr int AX19_THREADS = 768;                  // block size of attn_x3_k<19
 // The query-tile loop of the split-precision attention core: K (rotated) and V^T planes are in LDS (Kh / Kl / Vh / Vl, the layouts
 // above); every wave walks over 16-query tiles -- Q from global (fp32 rows, rotated, pre-scaled and split here), S^T = K Q^T, softmax,
 // O^T = V^T P^T, O rows out.  Shared by attn_x3_k (K / V staged from the projection's fp32 rows) and qkv_attn_x3_k
-// (hd_attn_fused.hip.h: K / V written straight from the projection's accumulators).  QL2: the Q rows were stored by other waves
-// of THIS workgroup a moment ago (qkv_attn_x3_k): they are read past the L1 (sc0), where a line of the previous launch could linger.
+// (hd_attn_fused.hip.h: K / V written straight from the projection's accumulators).  QL2 (qkv_attn_x3_k): Q arrives as ready-made MFMA
+// fragments that other waves of THIS workgroup stored a moment ago (rotated, scaled, split; 4 KiB per query tile at byte offset
+// `qoff` + tile x ldq x 4 of QKV): four coalesced loads per tile, past the L1 (sc1), where a line of the previous launch could linger.
 template <int KT, int NTH, bool QL2>
 __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, const char* Vh, const char* Vl, const float* __restrict__ QKV, int ldq,
                                               int qoff, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                               const __amdgpu_buffer_rsrc_t o_rs, int ldo, int b, int h, const Segs& sg, int o_split,
-                                              const RunState* __restrict__ rs, int lane, int wave) {
+                                              const RunState* __restrict__ rs, int lane, int wave, float* core_stamps = nullptr) {
     typedef AxGeom<KT> G;
+    // probe builds (-DHD_QA_STAMPS, scripts/r05/core_stamps.py): shader-clock stamps of this wave's first two query tiles -- tile start, Q fragment
+    // ready, S^T done, softmax done, O^T done, rows stored -- 16 floats per wave at core_stamps (nullptr in the product: folded away)
+    const unsigned long long cs_t0 = core_stamps ? __builtin_readcyclecounter() : 0ull;
+    int cs_tile = 0;
+    auto cstamp = [&](int k) {
+        if (core_stamps && cs_tile < 2 && lane == 0) core_stamps[wave * 16 + cs_tile * 6 + k] = (float)(__builtin_readcyclecounter() - cs_t0);
+    };
     constexpr int AX_KT = KT, AX_VKEYS = G::VKEYS, AX_VPLANE = G::VPLANE;
     constexpr bool EXACT = KT <= 10;
     const int L = sg.L;
@@ -1932,26 +1940,35 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
         vph[par] = Vh + qi * (AX_VKEYS * 2) + (G::vpos(4 * par + g, qi) << 4);
         vpl[par] = vph[par] + AX_VPLANE;
     }
+    typedef unsigned int u32x4_q __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t qf_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000);
+    f16x8 qh[2], ql[2];                                // Q fragment (B operand) of the current tile; QL2: loop-carried (the next tile's loads land here)
+    auto load_qf = [&](int qt) {
+        const uint32_t qb = (uint32_t)qoff + (uint32_t)qt * (uint32_t)ldq * 4u + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qh[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(qf_rs, (int)(qb + (uint32_t)(2 * ks) * 1024u), 0, 16));
+            ql[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(qf_rs, (int)(qb + (uint32_t)(2 * ks + 1) * 1024u), 0, 16));
+        }
+    };
+    if constexpr (QL2) { if (wave + (NTH / 64) * (int)blockIdx.y < nqt) load_qf(wave + (NTH / 64) * (int)blockIdx.y); }
     // (gridDim.y > 1: a few sequences -- the query tiles of a (sequence, head) are shared out over gridDim.y workgroups, each staging K and V)
     for (int qt = wave + (NTH / 64) * blockIdx.y; qt < nqt; qt += (NTH / 64) * gridDim.y) {
         const int q = qt * 16 + qi;
         const int qc = q < L ? q : L - 1;
         const long qrow = sg.row(b, qc);
+        cstamp(0);
         // Q fragment (B operand): lane holds Q[q][32 ks + 8 g + 0..7], rotated, pre-scaled by log2(e) / 8, split
-        f16x8 qh[2], ql[2];
         float vmax = 0.f;                              // range guard of this tile's Q split
+        // QL2: qkv_attn_x3_k stored the fragments themselves (its hand-over): four coalesced 1 KiB loads per tile, `qoff` = byte offset of the
+        // head's blocks in QKV, one row of ldq floats per tile; requested in front of the loop / behind the previous tile's S^T (load_qf)
+        if constexpr (!QL2)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int c4 = 32 * ks + 8 * g + 4 * hf;
-                f32x4 v;
-                if constexpr (QL2) {       // agent-scope (sc1) load: served by the L2 the same CU's stores were written through to
-                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-                    v = __builtin_bit_cast(f32x4, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(
-                            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QKV), 0, 0x7fffffff, 0x00020000),
-                            (int)(((uint32_t)qrow * (uint32_t)ldq + (uint32_t)(qoff + c4)) * 4u), 0, 16));
-                } else v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(QKV + qrow * ldq + qoff + c4);
                 const float2 cs = *reinterpret_cast<const float2*>(rope_cos + qc * 32 + (c4 >> 1));
                 const float2 sn = *reinterpret_cast<const float2*>(rope_sin + qc * 32 + (c4 >> 1));
                 constexpr float QS = 0.125f * 1.44269504088896340736f;
@@ -1966,6 +1983,7 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
             }
         }
         raise_range_flag(rs, vmax);
+        if (core_stamps) { asm volatile("" :: "v"(qh[0]), "v"(ql[1])); cstamp(1); }
         // S^T tiles (keys x queries), two key tiles per pass: two independent accumulator chains
         f32x4 st[AX_KT + 1];
 #pragma unroll
@@ -1994,6 +2012,11 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
             __builtin_amdgcn_sched_barrier(0);   // keep later tiles' LDS reads from being hoisted (VGPR pressure)
         }
         st[AX_KT] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (QL2) {                           // S^T is done with this tile's fragments: the next tile's travel under softmax and O^T
+            const int qn = qt + (NTH / 64) * (int)gridDim.y;
+            if (qn < nqt) load_qf(qn);
+        }
+        if (core_stamps) { asm volatile("" :: "v"(st[AX_KT - 1])); cstamp(2); }
         // softmax over keys (rows of S^T); this lane owns keys 16 kt + 4 g + r.  Scores live in the log2 domain.
         float mx = -INFINITY, sum = 0.f;
 #pragma unroll
@@ -2019,6 +2042,7 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
+        if (core_stamps) { asm volatile("" :: "v"(inv)); cstamp(3); }
         // O^T[d, q] = sum_key V^T[d, key] P^T[key, q], 32 keys per step: P of two S^T tiles is this lane's B operand as it is
         f32x4 oacc[4];
 #pragma unroll
@@ -2033,16 +2057,34 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ph[4 * q4 + e] = h4[e]; pl[4 * q4 + e] = l4[e]; }
             }
+            // two d tiles at a time, term by term: the three products of an accumulator are dependent MFMAs, and back to back they
+            // leave the matrix pipe idle for their latency (round-5 core stamps: 5 300 clocks for 120 MFMAs of 16).  Not in the 128-register
+            // instantiation attn_x3_k<10> (two more fragments: 7 spilled registers)
+            if constexpr (KT <= 10 && !QL2) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int ro = 128 * (t >> 1) + 16 * dt * (AX_VKEYS * 2);          // compile-time (t, dt unrolled)
-                const f16x8 vh = *reinterpret_cast<const f16x8*>(vph[t & 1] + ro), vl = *reinterpret_cast<const f16x8*>(vpl[t & 1] + ro);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int ro = 128 * (t >> 1) + 16 * dt * (AX_VKEYS * 2);          // compile-time (t, dt unrolled)
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(vph[t & 1] + ro), vl = *reinterpret_cast<const f16x8*>(vpl[t & 1] + ro);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[dt], 0, 0, 0);
+                }
+            } else
+#pragma unroll
+            for (int dp = 0; dp < 4; dp += 2) {
+                const int ro0 = 128 * (t >> 1) + 16 * dp * (AX_VKEYS * 2), ro1 = ro0 + 16 * (AX_VKEYS * 2);     // compile-time (t, dp unrolled)
+                const f16x8 vh0 = *reinterpret_cast<const f16x8*>(vph[t & 1] + ro0), vl0 = *reinterpret_cast<const f16x8*>(vpl[t & 1] + ro0);
+                const f16x8 vh1 = *reinterpret_cast<const f16x8*>(vph[t & 1] + ro1), vl1 = *reinterpret_cast<const f16x8*>(vpl[t & 1] + ro1);
+                oacc[dp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl0, ph, oacc[dp], 0, 0, 0);
+                oacc[dp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl1, ph, oacc[dp + 1], 0, 0, 0);
+                oacc[dp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh0, pl, oacc[dp], 0, 0, 0);
+                oacc[dp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh1, pl, oacc[dp + 1], 0, 0, 0);
+                oacc[dp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh0, ph, oacc[dp], 0, 0, 0);
+                oacc[dp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh1, ph, oacc[dp + 1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (core_stamps) { asm volatile("" :: "v"(oacc[3])); cstamp(4); }
         if (q < L) {
             // O rows through a buffer descriptor with 32-bit byte offsets (the launcher checks rows x ldq x 4 < 2 GiB, and ldo < ldq):
             // the 64-bit column offsets of plain pointers were loop invariants the 128-register instantiation had to spill
@@ -2067,6 +2109,8 @@ __device__ __forceinline__ void attn_x3_tiles(const char* Kh, const char* Kl, co
                 }
             }
         }
+        cstamp(5);
+        ++cs_tile;
     }
 }
 
