@@ -165,7 +165,7 @@ def synthetic_batch(kind: str, B: int, seed: int = 2023, mode: str | None = None
                 order=order, T=np.array(Ts, np.int32), truth=truth, mode=mode)
 
 
-ADVERSARIAL_VARIANTS = ("dc", "massive", "huge", "tiny")
+ADVERSARIAL_VARIANTS = ("dc", "massive", "huge", "tiny", "plain")
 
 
 def adversarial_state_dict(kind: str, cfg: dict, seed: int, variant: str) -> dict:
@@ -181,11 +181,15 @@ def adversarial_state_dict(kind: str, cfg: dict, seed: int, variant: str) -> dic
     ``huge``     the whole stream scaled by 2^17 (|x| ~ 1e6 > 65504, the fp16 range): embeddings, static branch and every
                  residual-branch output x 2^17, the un-normalised attention inputs / 2^17
     ``tiny``     the same with 2^-12 (|x| ~ 2e-3, row std ~ 3e-4 << 2^-3; below the LayerNorm epsilon)
+    ``plain``    nothing bent: the freshly initialised weights themselves (round 5: the control vector -- reference float32 / float64 logits
+                 and a short trace at production width with ordinary statistics)
 
     Used by oracle/make_golden_adversarial.py (loaded into the reference's classes) and by the parity tests."""
     if variant not in ADVERSARIAL_VARIANTS:
         raise ValueError(variant)
     sd = random_state_dict(kind, cfg, seed)
+    if variant == "plain":
+        return sd
     rng = np.random.default_rng(seed + 1000)
     last_w = ("sequence2.2.conv.weight", "out_put.weight", "ff_hl.2.weight")
     last_b = ("sequence2.2.conv.bias", "out_put.bias", "ff_hl.2.bias")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase time stamps of the fused Q|K|V + attention kernel (HUDIFF_QA_ABL=32): 100 MHz ticks since kernel entry per wave of the head-0 workgroups,
-read back from the unused V third of the QKV buffer.  python scripts/r05/fused_stamps.py [B]   (GPU box)"""
+read back from the unused V third of the QKV buffer.  python scripts/r05/fused_stamps.py [B] [ab|nb]   (GPU box)"""
 import os, sys
 import numpy as np
 os.environ["HUDIFF_QA_ABL"] = "32"
@@ -9,9 +9,11 @@ sys.path.insert(0, ROOT)
 import hudiff_amd
 from hudiff_amd import evalsets as E, synthetic as S
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-cfg = dict(S.AB_CONFIG); sd = S.random_state_dict("ab", cfg, seed=0)
-m = hudiff_amd.AntiTFNet(**cfg, precision="split", options={"fused_attn_min_grid": 0}); m.load_state_dict(sd)
-batch = E.eval_batch("huab348", B, row0=0)
+kind = sys.argv[2] if len(sys.argv) > 2 else "ab"
+cfg = dict(S.AB_CONFIG if kind == "ab" else S.NB_CONFIG); sd = S.random_state_dict(kind, cfg, seed=0)
+cls = hudiff_amd.AntiTFNet if kind == "ab" else hudiff_amd.NanoAntiTFNet
+m = cls(**cfg, precision="split", options={"fused_attn_min_grid": 0}); m.load_state_dict(sd)
+batch = E.eval_batch("huab348" if kind == "ab" else "vhh", B, row0=0)
 for stage, what in ((100, "first attention of block 0 (no LayerNorm fold)"), (3, "second attention of block 0 (LayerNorm folded)")):
     m.debug_stop_after(stage)
     m(batch["tokens"], batch["region"], batch["chain"], dropout="off")

@@ -11,7 +11,7 @@ import hudiff_oracle as ho
 from conftest import GOLDEN
 
 KINDS = ("ab", "nb")
-VARIANTS = ("dc", "massive", "huge", "tiny")
+VARIANTS = ("dc", "massive", "huge", "tiny", "plain")
 LOGIT_TOL = 1e-4
 
 
@@ -41,8 +41,10 @@ def test_fixture_statistics_are_what_they_claim(kind, variant):
         assert st["norm2_in"][1] > 1e4 and st["norm2_in"][1] < 32768
     elif variant == "huge":
         assert min(st[k][1] for k in st) > 65504
-    else:
+    elif variant == "tiny":
         assert max(st[k][1] for k in st) < 2.0 ** -8 and max(st[k][2] for k in st) < 2.0 ** -10
+    else:                                                                 # plain: the control -- ordinary statistics
+        assert max(st[k][1] for k in st) < 100 and max(st[k][0] for k in st) < 10
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
