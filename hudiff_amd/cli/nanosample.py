@@ -19,7 +19,7 @@ from .. import dist as D
 from .. import inputs as I
 from ..checkpoint import load_checkpoint, nanobody_model_from_checkpoint
 from ..model import NanoAntiTFNet
-from ..sampler import Job, sample_jobs_with_retry, seed_all
+from ..sampler import Job, noise_in_reference_order, sample_jobs_with_retry, seed_all
 from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_wrapped
 
 
@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument("--device_batch", type=int, default=256)
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful")
     p.add_argument("--device", type=int, default=None)
+    p.add_argument("--q_noise_fpath", type=str, default=None,
+                   help="parity aid: .npz whose array 'q' [draws, batch_size, 22] is the torch.multinomial noise a run of the reference "
+                        "recorded (input row by input row, step by step); replaces the library's counter-based noise for the first sweep")
     add_runtime_args(p)
     return p
 
@@ -110,9 +113,10 @@ def main(argv=None):
         if rank == 0:
             logger.info(I.untokenize_nanobody(row))
             logger.info("Need to re sample again.")
+    q_noise = noise_in_reference_order(np.load(args.q_noise_fpath)["q"], jobs, args.batch_size) if args.q_noise_fpath else None
     written = sample_jobs_with_retry(model, jobs, args.batch_size, args.seed, want=args.sample_number,
                                      tries=args.try_number, accept=lambda row: chain_is_valid(I.untokenize_nanobody(row)),
-                                     device_batch=args.device_batch, dropout=args.dropout, log=rejected)
+                                     device_batch=args.device_batch, dropout=args.dropout, log=rejected, q_noise=q_noise)
     if rank != 0:
         return None
     save_fpath = os.path.join(log_dir, "sample_humanization_result.csv")

@@ -26,7 +26,7 @@ from .. import dist as D
 from .. import inputs as I
 from ..checkpoint import antibody_model_from_checkpoint, load_checkpoint
 from ..model import model_selected
-from ..sampler import Job, sample_jobs, seed_all
+from ..sampler import Job, noise_in_reference_order, sample_jobs, seed_all
 from .common import add_runtime_args, relaunch_if_asked, get_logger, get_new_log_dir, load_numbered, split_fasta_for_save, write_fasta_2line
 
 
@@ -62,6 +62,9 @@ def build_parser():
     p.add_argument("--dropout", choices=["faithful", "off"], default="faithful",
                    help="faithful = the reference's inference-time dropout (active iff config.dropout > 0)")
     p.add_argument("--device", type=int, default=None)
+    p.add_argument("--q_noise_fpath", type=str, default=None,
+                   help="parity aid: .npz whose array 'q' [draws, batch_size, 22] is the torch.multinomial noise a run of the reference "
+                        "recorded (input row by input row, step by step); replaces the library's counter-based noise for the first pass")
     add_runtime_args(p)
     return p
 
@@ -203,8 +206,13 @@ def main(argv=None):
         args.sample_number = 0
         result = np.zeros((len(jobs), 0, args.batch_size, model.max_len), np.int32)
     else:
+        q_noise = None
+        if args.q_noise_fpath:
+            if passes != 1:
+                raise ValueError("--q_noise_fpath holds the noise of ONE pass over the input rows")
+            q_noise = noise_in_reference_order(np.load(args.q_noise_fpath)["q"], jobs, args.batch_size)
         result = sample_jobs(model, jobs, args.batch_size, args.seed, passes=passes, device_batch=args.device_batch,
-                             dropout=args.dropout)
+                             dropout=args.dropout, q_noise=q_noise)
     if rank != 0:
         return None
 

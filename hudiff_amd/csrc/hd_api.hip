@@ -80,6 +80,7 @@ struct Workspace {
     float *QKV = nullptr, *O = nullptr, *AT = nullptr, *F1 = nullptr;   // attention stage
     float *EXTRA = nullptr, *POS = nullptr, *PH = nullptr;   // static branch: [M,d], [M,d], [M,2d]
     float *S1 = nullptr, *YX = nullptr, *ATX = nullptr;      // split-precision route: act(LN(x)) of a ByteNet block's input; split copies of Y / AT, [M,D]
+    bool at_in_atx = false, o_is_split = false;              // what the launches issued last left (hd_debug_read): the second attention's sum only in ws.ATX; ws.O as X16 rows
     float2* ST = nullptr;
     int* SYNC = nullptr;                                     // ln_sync meeting counters, 4 ints per (segment, M tile): arrivals, departures, XCC-id mask, spare; zero between launches
     float2* PART[2] = {nullptr, nullptr};                    // ping-pong [PART_STRIDE][M] LayerNorm partials from GEMM epilogues
@@ -314,8 +315,19 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
         if (const char* e = getenv(d.env)) {
             const int64_t v = atoll(e);
             if (opt_legal(d, v)) m->opt[d.id] = v;
-            else if (d.nset == 0) m->opt[d.id] = v < d.lo ? d.lo : d.hi;        // out of range: clamped (as rounds 1-4 did)
+            else {
+                if (d.nset == 0) m->opt[d.id] = v < d.lo ? d.lo : d.hi;        // out of range: clamped (as rounds 1-4 did)
+                // (an old A/B script that exports a value this build no longer accepts must not measure the default against itself in silence)
+                if (!getenv("HUDIFF_QUIET"))
+                    fprintf(stderr, "[hudiff_hip] %s=%s is not a legal value of that option: %s %lld\n", d.env, e,
+                            d.nset == 0 ? "clamped to" : "ignored, the default stays", (long long)m->opt[d.id]);
+            }
         }
+    }
+    if (!getenv("HUDIFF_QUIET")) {                   // variables earlier rounds read and this build does not (INTEGRATION.md "Removed variables")
+        static const char* const removed[] = {"HUDIFF_GEMM_NBUF", "HUDIFF_PFF3_APPLY", "HUDIFF_ENC_FUSED", "HUDIFF_GEMM_SMALL", "HUDIFF_ST_NT", "HUDIFF_ENC_ABL"};
+        for (const char* r : removed)
+            if (getenv(r)) fprintf(stderr, "[hudiff_hip] %s is set, but this build has no such switch any more: ignored\n", r);
     }
     m->device = device;
     m->nseg = c.kind == HD_KIND_ANTIBODY ? 2 : 1;
@@ -959,8 +971,12 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         if (!per_seg) { run.nseg = 1; run.len[0] = p.sg.L; run.off[0] = 0; run.base[0] = 0; }
         GemmP q = p;
         q.sg = run;
+#ifdef HD_PROBES
         static const int abl = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e ? atoi(e) : 0; }();
-        q.x3_abl = abl | ((m->debug_lnsync_fail && q.ln_sync) ? 128 : 0) | ((m->debug_lnsync_scatter && q.ln_sync) ? 256 : 0);
+        q.x3_abl = abl;
+#endif
+        static const int full_epi = [] { const char* e = getenv("HUDIFF_X3_ABL"); return e && (atoi(e) & 64) ? 4 : 0; }();      // (tests: the all-features epilogue everywhere)
+        q.dbg = ((m->debug_lnsync_fail && q.ln_sync) ? 1 : 0) | ((m->debug_lnsync_scatter && q.ln_sync) ? 2 : 0) | full_epi;
         const int rows0 = run.B * run.len[0], rows1 = run.nseg > 1 ? run.B * run.len[1] : 0;
         // tile shape / pipeline depth, by measurement: 256 x 256 tiles (two stages, one 8-wave block per CU)
         // for the widest output (Q|K|V, N = 1536: 621 vs 650 us), two stages of 128 x 128 tiles (two blocks per CU) elsewhere; three
@@ -969,7 +985,8 @@ static void launch_gemm(HdModel* m, GemmP& p, bool conv, bool per_seg, int stats
         const long t256 = (rows0 + 255) / 256 + (rows1 + 255) / 256;
         int shape = (q.N % 256 == 0 && q.N >= 1024 && t256 * (q.N / 256) >= 384) ? 512 : 128;
         if (force == 128 || force == 256 || (force == 512 && q.N % 256 == 0)) shape = force;
-        if (q.ln_sync) shape = 128;                     // the meeting epilogue exists in the 4-wave 128 x 128 instantiation only
+        if (q.ln_sync) shape = 128;                     // (never the 8-wave tiles: every 4-wave instantiation -- 128, 64 and 32 rows, EPISET 0 / 2 -- carries the meeting epilogue,
+                                                        //  so the small_grid / tiny_grid downgrades below keep an ln_sync launch legal)
         // under-filled grids (mid-size batches): 64 x 128 tiles double the blocks of a launch whose 128 x 128 grid leaves CUs idle or
         // with one latency-bound block each.  HD_OPT_SMALL_GRID = largest 128 x 128 grid that takes them (320: B = 8 antibodies
         // 20.0 -> 25.1 sequences/s, B = 16 36.5 -> 42.4, B = 48 73.3 -> 78.4; larger limits lose again).
@@ -1214,8 +1231,10 @@ static void attention_layer(HdModel* m, const Segs& sg, const AttLayerW& w, cons
         q.ln_fold = p.ln_fold; q.stats = p.stats; q.spart = p.spart; q.spw = p.spw; q.spart_rows = p.spart_rows;
         q.QKV = cur(m).ws.QKV; q.ldq = 3 * A; q.att = A; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.rope_cs = m->rope_cs;
         q.O = cur(m).ws.O; q.ldo = A; q.nhead = m->cfg.nhead; q.sg = sg; q.rs = cur(m).rs;
-        static const int qa_abl = [] { const char* e = getenv("HUDIFF_QA_ABL"); return e ? atoi(e) : 0; }();      // (probes only)
+#ifdef HD_PROBES
+        static const int qa_abl = [] { const char* e = getenv("HUDIFF_QA_ABL"); return e ? atoi(e) : 0; }();
         q.abl = qa_abl;
+#endif
         const int NH = fuse19 ? 1 : 2;
         dim3 fgrid((unsigned)(((sg.B + 7) / 8) * 8 * (m->cfg.nhead / NH)));
         if (fuse19) hipLaunchKernelGGL((qkv_attn_x3_k<19, 1>), fgrid, dim3(QA_THREADS), lds_request(QaGeom<19, 1>::smem(m->L), QA_THREADS), st, q);
@@ -1410,12 +1429,14 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
         const AttBlockW& w = m->att[n];
         // at = x + A1(x)
         attention_layer(m, sg, w.a1, ws.Y, false, ws.Y, ws.AT, /*want_out_stats=*/true, ax3, ws.YX, ws.ATX);
+        ws.at_in_atx = false; ws.o_is_split = ax3;
         if (m->debug_stop_after == 100 + n) return HD_OK;        // (tests: right behind the first attention of block n)
         // at = at + A2(LN1(at))      (statistics of `at` come from the out-projection's epilogue)
         if (prune_last && n == c.cs_layers - 1) { pruned_tail(m, sg, w); break; }
         // (split route: FF1 is the only reader of this sum -- the block's last residual comes from the block INPUT -- and reads it in split
         //  form, so the fp32 rows are not written: 229 MB per launch at 256 antibodies)
         attention_layer(m, sg, w.a2, ws.AT, true, ws.AT, ws.AT, /*want_out_stats=*/true, ax3, ws.ATX, ws.ATX, /*split_only=*/ax3);
+        ws.at_in_atx = ax3;
         // x = FF(LN2(at)) + x       (residual from the block INPUT, cross_attention.py:282-286)
         GemmP p = base_gemm(m, sg);
         p.A = ws.AT; p.lda = D; p.W = w.wf1; p.bias = w.bf1; p.C = ws.F1; p.ldc = m->Fd; p.N = m->Fd; p.Kc = D;
@@ -1952,15 +1973,20 @@ extern "C" HdStatus hd_debug_stop_after(HdModel* m, int32_t stage) {
 extern "C" HdStatus hd_debug_fail_next_lnsync(HdModel* m) {
     if (!m) return fail(HD_ERR_INVALID, "hd_debug_fail_next_lnsync: null model");
     m->debug_lnsync_fail = true;   // the ln_sync meetings of the kernels launched / captured next give up after one poll
-    for (auto& ln : m->lane) ln.drop_graphs();
+    if (m->finalized) {
+        HIP_TRY(hipSetDevice(m->device));
+        for (auto& ln : m->lane) { if (ln.stream) hipStreamSynchronize(ln.stream); ln.drop_graphs(); }
+    }
     return HD_OK;
 }
 
 extern "C" HdStatus hd_debug_scatter_lnsync(HdModel* m, int32_t on) {
     if (!m) return fail(HD_ERR_INVALID, "hd_debug_scatter_lnsync: null model");
+    if (!m->finalized) return fail(HD_ERR_STATE, "hd_debug_scatter_lnsync: call hd_finalize first");
     if (m->in_session) return fail(HD_ERR_STATE, "hd_debug_scatter_lnsync: a sampling session is open");
     m->debug_lnsync_scatter = on != 0;
-    for (auto& ln : m->lane) ln.drop_graphs();
+    HIP_TRY(hipSetDevice(m->device));                // hd_set_option's sequence: nothing captured with the old placement may still be in flight
+    for (auto& ln : m->lane) { if (ln.stream) hipStreamSynchronize(ln.stream); ln.drop_graphs(); }
     return HD_OK;
 }
 
@@ -1971,20 +1997,35 @@ extern "C" HdStatus hd_debug_read(HdModel* m, const char* name, int32_t B, float
     const std::string k(name);
     const float* src = nullptr;
     int width = 0;
+    bool x16 = false;                                             // rows are X16 split rows (x16_hi(): per 16 columns 16 fp16 high parts, then 16 low parts)
     if (k == "FEAT") { src = ws.FEAT; width = m->D; }
     else if (k == "Y") { src = ws.Y; width = m->D; }
     else if (k == "X") { src = ws.X; width = m->d; }
     else if (k == "POS") { src = ws.POS; width = m->d; }
     else if (k == "EXTRA") { src = ws.EXTRA; width = m->d; }
-    else if (k == "AT") { src = ws.AT; width = m->D; }
-    else if (k == "O") { src = ws.O; width = m->A; }              // (split route: X16 rows -- per 32 columns 32 fp16 high parts, then 32 low parts)
+    // "AT": at = x + A1(x) behind the first attention of a block, at + A2(LN1(at)) behind the second.  On the split route the second sum
+    // exists in split form only (ws.ATX: FF1 is its one reader), so it is decoded from there (hi + lo: 22 significand bits) -- the name
+    // means the same tensor on every route.  "ATX" / "YX" / "O": decoded split rows as well when the split route wrote them.
+    else if (k == "AT") { src = ws.at_in_atx ? ws.ATX : ws.AT; x16 = ws.at_in_atx; width = m->D; }
+    else if (k == "ATX") { src = ws.ATX; x16 = true; width = m->D; }
+    else if (k == "YX") { src = ws.YX; x16 = true; width = m->D; }
+    else if (k == "O") { src = ws.O; x16 = ws.o_is_split; width = m->A; }
     else if (k == "QKV") { src = ws.QKV; width = 3 * m->A; }
     else return fail(HD_ERR_INVALID, "hd_debug_read: unknown buffer %s", name);
+    if (!src) return fail(HD_ERR_STATE, "hd_debug_read: buffer %s does not exist on this handle's route", name);
     if (B > ws.capB || n_floats != (int64_t)B * m->L * width) return fail(HD_ERR_INVALID, "hd_debug_read: size mismatch");
     // rows are segment-major on the device; return them as [B, L, width]
     std::vector<float> tmp((size_t)n_floats);
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    if (x16) {
+        std::vector<float> row((size_t)width);
+        for (size_t r = 0; r < (size_t)B * m->L; ++r) {
+            const _Float16* h = reinterpret_cast<const _Float16*>(tmp.data() + r * width);
+            for (int c = 0; c < width; ++c) row[c] = (float)h[x16_hi(c)] + (float)h[x16_hi(c) + X16_LO];
+            memcpy(tmp.data() + r * width, row.data(), sizeof(float) * width);
+        }
+    }
     const Segs sg = make_segs(m, B);
     for (int b = 0; b < B; ++b)
         for (int l = 0; l < m->L; ++l)

@@ -37,9 +37,11 @@ struct QkvAttnP {
     const float* rope_cs;                          // the same table interleaved, [L][32] x (cos, sin): one 16-byte load per two RoPE pairs
     float* O; int ldo;                             // attention output rows, X16 split form [rows, att]
     int nhead; Segs sg; const RunState* rs;
-    int abl;                                       // probes only (HUDIFF_QA_ABL): 1 no MFMAs in the projection, 2 no operand DMA after the first tile,
+#ifdef HD_PROBES
+    int abl;                                       // probe builds only (-DHD_PROBES, HUDIFF_QA_ABL): 1 no MFMAs in the projection, 2 no operand DMA after the first tile,
                                                    // 4 no attention core, 8 no hand-over of K / V into the planes, 32 phase time stamps (100 MHz
                                                    // ticks since kernel entry, per wave of the head-0 workgroups) into the unused V third of QKV
+#endif
 };
 
 constexpr int QA_THREADS = 768, QA_WAVES = 12;
@@ -89,9 +91,9 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
     const int rA1 = p.sg.nseg > 1 ? p.sg.base[1] + b * p.sg.len[1] - p.sg.off[1] : rA0;
     const int roff1 = p.sg.nseg > 1 ? p.sg.off[1] : 0x7fffffff;
     const int nkt = p.ldx / X3_BK;
-    const unsigned long long t_entry = (p.abl & 32) ? wall_clock64() : 0ull;
+    const unsigned long long t_entry = (HD_QABL(p) & 32) ? wall_clock64() : 0ull;
     auto stamp = [&](int k) {                          // probe (abl bit 5): phase k of this wave, head-0 workgroups only
-        if ((p.abl & 32) && h0 == 0 && lane == 0)
+        if ((HD_QABL(p) & 32) && h0 == 0 && lane == 0)
             p.QKV[(long)(rA0 + p.sg.off[0]) * p.ldq + 2 * p.att + wave * 8 + k] = (float)(wall_clock64() - t_entry);
     };
     float* rstd_s = reinterpret_cast<float*>(qas + Q::RSTD_OFF);
@@ -218,9 +220,9 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
         // The matrix pipe then has eighteen MFMAs per SIMD to run while the first LDS reads of the new tile are under way, instead of
         // draining at every barrier and idling for a read round trip behind it (tile stamps, NOTES.md D: ~600 of a tile's ~3 900 clocks).
         // Order of the products inside every accumulator: unchanged.
-        if (p.abl & 1) {                               // probe: no MFMAs (and no fragment reads)
+        if (HD_QABL(p) & 1) {                               // probe: no MFMAs (and no fragment reads)
             for (int kt = 0, st = 0; kt < nkt; ++kt, st ^= 1) {
-                if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
+                if (kt + 1 < nkt && !(HD_QABL(p) & 2)) dma(kt + 1, st ^ 1);
                 __builtin_amdgcn_s_waitcnt(WAIT_ALL);
                 lds_barrier();
             }
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
                 const char* At = qas + st * STAGE + rg * TM * 32 * 128;
                 const char* Wt = qas + st * STAGE + A_BYTES + ct * 32 * 64;
                 // the other stage was read in tile kt - 1 and every wave is past that tile's barrier
-                if (kt + 1 < nkt && !(p.abl & 2)) dma(kt + 1, st ^ 1);
+                if (kt + 1 < nkt && !(HD_QABL(p) & 2)) dma(kt + 1, st ^ 1);
 #ifdef HD_QA_STAMPS
                 if (kt == 10) ts[1] = (uint32_t)__builtin_readcyclecounter();
 #endif
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
         char* Vh = planes + 2 * krows * 128;
         char* Vl = Vh + G::VPLANE;
         float vmax = 0.f;                              // range guard: K and V are split from fp32 values here (X16_LIMIT)
-        if (p.abl & 8) {
+        if (HD_QABL(p) & 8) {
         } else if constexpr (PART == 1) {
             // cos, sin, cos, sin of the two RoPE pairs of head dimensions d0 .. d0 + 3 (one 16-byte load); the table rows of tile i + 1 are
             // requested before tile i is rotated (two tiles = 32 registers in flight: five serial round trips were most of this phase;
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(QA_THREADS, 3) qkv_attn_x3_k(const QkvAttnP p)
 
     // ---- attention core -------------------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(p.O, 0, 0x7fffffff, 0x00020000);
-    if (p.abl & 4) return;
+    if (HD_QABL(p) & 4) return;
 #pragma unroll
     for (int hx = 0; hx < NH; ++hx) {
         const char* pl = qas + hx * Q::planes(L);

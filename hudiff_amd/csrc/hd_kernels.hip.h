@@ -40,6 +40,16 @@ namespace hd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Probe code (ablation bits inside the kernels' loops) exists only in -DHD_PROBES builds (a separate .so, selected with HUDIFF_LIB);
+// in the default build HD_ABL() / HD_QABL() are the constant 0 and every branch on them is compiled out.
+#ifdef HD_PROBES
+#define HD_ABL(p) ((p).x3_abl)
+#define HD_QABL(p) ((p).abl)
+#else
+#define HD_ABL(p) 0
+#define HD_QABL(p) 0
+#endif
+
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 enum { DROP_NONE = 0, DROP_GEN = 1, DROP_INJECT = 2 };
 constexpr int PART_STRIDE = 32;   // max column slices of a GEMM output row (N <= 1024 with 32-wide slices)
@@ -193,9 +203,14 @@ struct GemmP {
     // carries no conversion.
     int st_nt;                        // fp32 kernels: epilogue stores carry the non-temporal policy (gemm_x3_k always stores non-temporally:
                                       // streamed outputs then do not displace operand lines in L2)
-    int x3_abl;                       // ablation (HUDIFF_X3_ABL, probes only): 1 = no MFMAs, 2 = no operand DMA after the first tiles,
-                                      // 3 = neither (epilogue only), 4 = one LDS fragment read per k step; bit 7 (128): ln_sync meetings
-                                      // give up after one poll (hd_debug_fail_next_lnsync: exercises the ln_sync guard)
+#ifdef HD_PROBES
+    int x3_abl;                       // probe builds only (-DHD_PROBES, HUDIFF_X3_ABL; scripts/r05/ab_env.sh): 1 = no MFMAs, 2 = no operand DMA after
+                                      // the first tiles, 3 = neither (epilogue only), 4 = one LDS fragment read per k step, bit 3 = no epilogue,
+                                      // bit 5 = no stores.  The default build has neither the field nor the branches.
+#endif
+    int dbg;                          // test aids (hd_debug_*): bit 0 = ln_sync meetings give up after one poll (hd_debug_fail_next_lnsync: exercises
+                                      // the ln_sync guard), bit 1 = the N tiles of an M tile on DIFFERENT XCDs (hd_debug_scatter_lnsync),
+                                      // bit 2 = every launch takes the all-features epilogue (HUDIFF_X3_ABL=64 at process start; tests)
     int c_split;                      // epilogue: C is written in split form (ldc == N), no fp32 copy
     float* C2;                        // epilogue: additional split copy of the output rows, row stride N (may be null)
     const float* bias;                // [N], per segment at + seg * n_stride (may be null)
@@ -482,7 +497,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
             const int rr = it * RPI + e_r;
             const int g0 = wrow0 + 32 * i + it * RPI;                           // uniform
             const int lrow = g0 + e_r;
-            const bool valid = lrow < seg_rows && col_ok && !(p.x3_abl & 32);      // probe bit 5: every store switched off
+            const bool valid = lrow < seg_rows && col_ok && !(HD_ABL(p) & 32);    // (probe bit 5: every store switched off)
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + rr * ES + e_c4);
             if (valid) {
                 if ((F & EPI_X3) || p.Wx) v *= acc_scale;                               // split-precision operands were scaled by powers of two
@@ -606,8 +621,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[BM /
                 __hip_atomic_fetch_or(ctr + 2, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // ~1 s of polling: far beyond any launch; then give up loudly (the host repeats the call with ln_apply_k passes).
-                // Probe bit 7 of x3_abl (hd_debug_fail_next_lnsync, tests only): a budget of one poll, so that the guard's path runs
-                int budget = (p.x3_abl & 128) ? 1 : (1 << 20);
+                // GemmP::dbg bit 0 (hd_debug_fail_next_lnsync, tests only): a budget of one poll, so that the guard's path runs
+                int budget = (p.dbg & 1) ? 1 : (1 << 20);
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.tiles_n && --budget > 0)
                     __builtin_amdgcn_s_sleep(1);
                 const int seen = __hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1136,13 +1151,13 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
         const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;        // all N tiles of an M tile on one XCD (see gemm_k)
         by = slot % p.tiles_n;
         bx = (slot / p.tiles_n) * 8 + xcd;
-        // test aid (hd_debug_scatter_lnsync, probe bit 8): consecutive workgroups -- which go to DIFFERENT XCDs -- are the N tiles of an
+        // test aid (hd_debug_scatter_lnsync, GemmP::dbg bit 1): consecutive workgroups -- which go to DIFFERENT XCDs -- are the N tiles of an
         // M tile, so that the ln_sync meeting runs its cross-XCD path (same results, tests/test_gpu_x3.py)
-        if (p.x3_abl & 256) { by = b % p.tiles_n; bx = b / p.tiles_n; }
+        if (p.dbg & 2) { by = b % p.tiles_n; bx = b / p.tiles_n; }
         if (bx >= p.tiles_m) return;
     }
     if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
-    const int abl_mode = p.x3_abl & 7;                 // probes only (scripts/x3_probe.hip); bit 3 = no epilogue, bit 5 = no stores
+    const int abl_mode = HD_ABL(p) & 7;               // (0 unless -DHD_PROBES)
     const int Lc = p.sg.len[seg];
     const int seg_rows = p.sg.B * Lc;
     const int rbase = p.sg.base[seg];
@@ -1378,7 +1393,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     // NOT ended arrived, so the four MFMA waves synchronise among themselves; the static_assert at the top of this file pins the
     // target this relies on.
     if (LW > 0 && loader) return;
-    if (p.x3_abl & 8) {                                // probe: no epilogue (the accumulators stay live through a never-true store)
+    if (HD_ABL(p) & 8) {                               // probe: no epilogue (the accumulators stay live through a never-true store)
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1391,7 +1406,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + LW), (WM * WN == 4 && NS <= 3 
     }
     // the smallest feature mask that covers this launch (uniform): PFF1 / tap GEMM, Q|K|V, FF1, out-projection / FF2, the rest
     const float2* rowst = reinterpret_cast<const float2*>(smem + WORK_FLOATS);
-    const int need = p.x3_abl & 64 ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);
+    const int need = (p.dbg & 4) ? (EPI_ALL | (epi_needs(p) & EPI_LNSYNC)) : epi_needs(p);      // (dbg bit 2: test_x3_feature_masked_epilogues_change_nothing)
 #define HD_EPI(F) gemm_epilogue<BM, BN, WM, WN, (F) | EPI_X3, PRE>(p, acc, smem, rowst, seg, seg_rows, rbase, Lc, m0, n0, by, &pre)
     if (need & EPI_LNSYNC) {
         // (only the 4-wave 128 x 128 instantiation is ever launched with ln_sync; the others keep the code out)

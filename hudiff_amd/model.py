@@ -335,7 +335,7 @@ class _Denoiser:
         L.check(self._lib.hd_debug_stop_after(self._h, int(stage)))
 
     def debug_read(self, name, B):
-        width = {"FEAT": "sum_d_model", "Y": "sum_d_model", "AT": "sum_d_model", "O": "att_model"}.get(name, "d_model")
+        width = {"FEAT": "sum_d_model", "Y": "sum_d_model", "AT": "sum_d_model", "ATX": "sum_d_model", "YX": "sum_d_model", "O": "att_model"}.get(name, "d_model")
         w = 3 * self.config["att_model"] if name == "QKV" else self.config[width]
         out = np.empty((B, self.max_len, w), dtype=np.float32)
         L.check(self._lib.hd_debug_read(self._h, name.encode(), B, L.ptr(out, C.c_float), out.size))

@@ -81,7 +81,7 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
         chain = np.array([j.chain[0] for j in jb] + [j.chain[1] for j in jb], np.int32) if is_ab else None
         for p in range(passes):
             tok = model.sample(tok, reg, chain, order, T, seed=seed + 1000003 * p, row0=int(gids[cs]), dropout=dropout,
-                               q_noise=None if q_noise is None else q_noise[p][:, s:e])
+                               q_noise=None if q_noise is None else np.ascontiguousarray(q_noise[p][:Tmax, gids[cs:ce]]))
             out[p, s - lo:e - lo] = tok
     gathered = [D.gather_rows(out[p], n_rows, L, all_ranks) for p in range(passes)]
     if gathered[0] is None:
@@ -89,8 +89,27 @@ def sample_jobs(model, jobs: Sequence[Job], replicas: int, seed: int, *, passes:
     return np.stack(gathered, axis=0).reshape(passes, len(jobs), replicas, L).transpose(1, 0, 2, 3)
 
 
+def noise_in_reference_order(q_flat, jobs: Sequence[Job], replicas: int) -> np.ndarray:
+    """Recorded ``torch.multinomial`` noise of a REFERENCE run -> the ``q_noise`` argument of ``sample_jobs``.
+
+    The reference draws input row by input row, step by step, one ``[batch_size, 22]`` Exp(1) tensor per step
+    (sample.py:499-513, nanosample.py:316-329): ``q_flat`` is that sequence, ``[sum_j T_j, replicas, 22]`` for ONE sweep over
+    every input row.  Here row (job j, replica r) is global row ``j * replicas + r`` -> ``[1, Tmax, len(jobs) * replicas, 22]``."""
+    q_flat = np.asarray(q_flat, np.float32)
+    Ts = [len(j.loc) for j in jobs]
+    if q_flat.shape != (sum(Ts), replicas, 22):
+        raise ValueError(f"recorded noise has shape {q_flat.shape}; this input needs {(sum(Ts), replicas, 22)} "
+                         "(one [batch_size, 22] draw per visited slot of every input row)")
+    out = np.ones((1, max(Ts + [1]), len(jobs) * replicas, 22), np.float32)
+    at = 0
+    for j, T in enumerate(Ts):
+        out[0, :T, j * replicas:(j + 1) * replicas] = q_flat[at:at + T]
+        at += T
+    return out
+
+
 def sample_jobs_with_retry(model, jobs: Sequence[Job], replicas: int, seed: int, *, want: int, tries: int, accept,
-                           device_batch: int = 256, dropout: str = "faithful", log=None) -> List[List[np.ndarray]]:
+                           device_batch: int = 256, dropout: str = "faithful", log=None, q_noise=None) -> List[List[np.ndarray]]:
     """The nanobody sampler's accept / re-sweep loop (nanobody_scripts/nanosample.py:316-353), batched.
 
     Per input sequence the reference keeps ``sample_number`` (rows still wanted) and ``try_num``: while both are
@@ -107,8 +126,9 @@ def sample_jobs_with_retry(model, jobs: Sequence[Job], replicas: int, seed: int,
                    loc=jobs[j].loc, chain=jobs[j].chain, name=jobs[j].name) for j in active]
         # noise is keyed by the ORIGINAL job index: a sequence's samples do not depend on which other inputs were
         # accepted earlier (or are in the file at all)
+        # (q_noise: injected noise of sweep 0 only, [1, Tmax, len(jobs) * replicas, 22] keyed like the generated noise: parity runs)
         res = sample_jobs(model, sub, replicas, seed + 1000003 * sweep, device_batch=device_batch, dropout=dropout,
-                          all_ranks=True, job_ids=active)
+                          all_ranks=True, job_ids=active, q_noise=q_noise if sweep == 0 else None)
         still = []
         for a, j in enumerate(active):
             st = state[j]

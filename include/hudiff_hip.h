@@ -261,8 +261,11 @@ HdStatus hd_device_info(int device, char* name, size_t name_len, int32_t* cu_cou
 
 /* ---- debugging aids (tests only) -----------------------------------------------------------------
  * hd_debug_stop_after: make hd_forward return after a stage (0 = off, 1 = token encoder, 2+n = before
- * attention block n); hd_debug_read copies an activation buffer ("X","FEAT","Y","POS","EXTRA","AT") of
- * the last call back as [B, L, width]. */
+ * attention block n, 100+n = right behind the first attention of block n); hd_debug_read copies an activation
+ * buffer ("X","FEAT","Y","POS","EXTRA","AT","O","QKV"; split route also "ATX","YX") of the last call back as fp32
+ * [B, L, width].  "AT" is x + A1(x) behind a block's first attention and at + A2(LN1(at)) behind its second on every
+ * route: the split route keeps the second sum in split form only and the call decodes it (hi + lo); "O", "ATX",
+ * "YX" are decoded the same way when the split kernels wrote them. */
 HdStatus hd_debug_stop_after(HdModel* m, int32_t stage);
 /* Makes the ln_sync meetings of the next call give up after one poll, so that the ln_sync guard (see "precision routes") fires and
  * its repeat path can be tested; cleared when the guard has fired. */

@@ -109,7 +109,9 @@ class TorchOracleNet(ho.OracleNet):
     def _self_att_block(self, x, n):
         pre = f"self_at.layers.{n}."
         at = x + self._attn(x, pre + "attn_hl.")
+        self._rec(f"att{n}_at1", at.numpy())
         at = at + self._attn(self._ln(at, pre + "norm_hl1"), pre + "attn_hl_c.")
+        self._rec(f"att{n}_at2", at.numpy())
         f = self.F.relu(self._lin(self._ln(at, pre + "norm_hl2"), pre + "ff_hl.0"))
         return self._lin(f, pre + "ff_hl.2") + x
 
@@ -122,16 +124,22 @@ class TorchOracleNet(ho.OracleNet):
             assert tok.shape[1] == self.L
             e = self.tw["aa_encoder.embedder.weight"][tok]
             e = self._conv_stack(e, "aa_encoder", self.enc_dil, self.enc_act, self.p_enc, "enc", drop)
+            self._rec("aa_encoder", e.numpy())             # (the same trace keys as hudiff_oracle.OracleNet.forward)
             pos, chn = static if static is not None else self.static_embed(region, chain)
+            self._rec("pos", pos.numpy())
             if self.kind == "ab":
+                self._rec("chn", chn.numpy())
                 feat = torch.cat([e + pos + chn, pos, chn], dim=-1)
             else:
                 feat = torch.cat([e + pos, pos], dim=-1)
             p_conv = 0.5 if self.p_enc > 0.0 else 0.0
             h = self._conv_stack(feat, self.conv_prefix, self.conv_dil, self.conv_act, p_conv, "conv", drop)
+            self._rec("conv", h.numpy())
             for n in range(int(self.cfg["cs_layers"])):
                 h = self._self_att_block(h, n)
+                self._rec(f"att{n}", h.numpy())
             h = self._ln(h, "last_norm")
+            self._rec("last_norm", h.numpy())
             return self._lin(h, "decoder").numpy()
 
     __call__ = forward

@@ -74,7 +74,29 @@ def main():
         tokens[1, fill] = rng.integers(0, 22, size=len(fill))
         if kind == "ab":
             chain = np.array([0, 0, 2, 1], np.int64)
+        # per-component activations of the same forward (round 6: tests/test_gpu_components.py holds the HIP buffers to them row by row
+        # of SURVEY.md section 8a): forward hooks on the reference's own sub-modules, written to a SEPARATE file so that deep_{kind}.npz
+        # regenerates bit for bit as before
+        acts, hooks = {}, []
+
+        def grab(key):
+            def hook(mod, inp, out):
+                o = out if not isinstance(out, (tuple, list)) else torch.cat(list(out), dim=1)       # DualConv returns (h, l)
+                acts[key] = o.detach().numpy().astype(np.float32)
+            return hook
+        conv_name = "dual_conv_block" if kind == "ab" else "nano_conv_block"
+        for mod_name, key in (("aa_encoder", "aa_encoder"), ("region_encoder", "region"), ("pos_encoder", "pos"), (conv_name, "conv"),
+                              ("last_norm", "last_norm")) + ((("side_encoder", "side"),) if kind == "ab" else ()):
+            hooks.append(getattr(model0, mod_name).register_forward_hook(grab(key)))
+        for n, layer in enumerate(model0.self_at.layers):
+            hooks.append(layer.register_forward_hook(grab(f"att{n}")))
+            hooks.append(layer.attn_hl.register_forward_hook(grab(f"att{n}_a1")))          # AttLayer output (before the residual)
         logits = mg.ref_forward(model0, tokens, region, chain)
+        for h in hooks:
+            h.remove()
+        np.savez_compressed(os.path.join(OUT, f"deep_{kind}_acts.npz"), weight_sha256=np.array(weights_digest(sd)),
+                            **{"act_" + k: v for k, v in acts.items()})
+        print(kind, "component activations:", {k: v.shape for k, v in acts.items()})
         torch.manual_seed(4321)
         with mg.Recorder() as rec:
             logits_d = mg.ref_forward(model1, tokens, region, chain)
