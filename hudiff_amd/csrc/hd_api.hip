@@ -325,7 +325,7 @@ extern "C" HdStatus hd_create(const HdConfig* cfg, int device, HdModel** out) {
         }
     }
     if (!getenv("HUDIFF_QUIET")) {                   // variables earlier rounds read and this build does not (INTEGRATION.md "Removed variables")
-        static const char* const removed[] = {"HUDIFF_GEMM_NBUF", "HUDIFF_PFF3_APPLY", "HUDIFF_ENC_FUSED", "HUDIFF_GEMM_SMALL", "HUDIFF_ST_NT", "HUDIFF_ENC_ABL"};
+        static const char* const removed[] = {"HUDIFF_GEMM_NBUF", "HUDIFF_PFF3_APPLY", "HUDIFF_ENC_FUSED", "HUDIFF_ENC_ABL", "HUDIFF_X3_PERSIST"};
         for (const char* r : removed)
             if (getenv(r)) fprintf(stderr, "[hudiff_hip] %s is set, but this build has no such switch any more: ignored\n", r);
     }
