@@ -729,8 +729,34 @@ def main():
             evidence["token_agreement"][f"{route_main} vs f32_all"] = agreement(main_tokens, fp32_tokens)
         if f32_gemm is not None:
             evidence["token_agreement"][f"{route_main} vs f32_gemm"] = f32_gemm["token_agreement_with_top_level"]
+        # ---- rows identical to the REFERENCE: tests/golden/fliprate_{kind}.npz holds 64 complete production-width samples drawn by the
+        # reference's own AntiTFNet / NanoAntiTFNet on the CPU (same seed-0 weights as this run; oracle/make_golden_fliprate.py), with the
+        # torch.multinomial noise it used and its near-tie margin of every draw; replayed here on the open models (dropout off, as recorded)
+        try:
+            import hashlib
+            fz = np.load(os.path.join(ROOT, "tests", "golden", f"fliprate_{kind}.npz"))
+            h = hashlib.sha256()
+            for k in sorted(sd):
+                h.update(k.encode())
+                h.update(np.ascontiguousarray(sd[k], dtype=np.float32).tobytes())
+            if h.hexdigest() == str(fz["weight_sha256"]):
+                ftok, freg, fT = fz["tokens"].astype(np.int64), fz["region"].astype(np.int64), fz["T"].astype(np.int64)
+                fch = fz["chain"].astype(np.int64) if fz["chain"].size else None
+                rep = {"source": f"tests/golden/fliprate_{kind}.npz: {ftok.shape[0]} rows sampled by the reference (PyTorch CPU, float32), recorded noise", "routes": {}}
+                for r, mdl in routes.items():
+                    got = np.asarray(mdl.sample(ftok, freg, fch, fz["order"].astype(np.int64), fT, q_noise=fz["q"], dropout="off"))
+                    diff = []
+                    for b in range(ftok.shape[0]):
+                        slots = fz["order"][b, :int(fT[b])]
+                        bad = np.nonzero(got[b, slots] != fz["final"][b, slots])[0]
+                        if bad.size:
+                            diff.append({"row": int(b), "first_differing_step": int(bad[0]), "reference_margin_of_that_draw": float(f"{float(fz['margin'][b, bad[0]]):.3e}")})
+                    rep["routes"][r] = {"rows_identical_to_the_reference": f"{ftok.shape[0] - len(diff)} of {ftok.shape[0]}", "differing": diff}
+                evidence["reference_rows"] = rep
+        except (OSError, KeyError) as e:
+            evidence["reference_rows"] = {"skipped": repr(e)}
         evidence["precision_info_after"] = {r: mdl.precision_info() for r, mdl in routes.items()}
-        phase("precision evidence (float64 oracle)")
+        phase("precision evidence (float64 oracle, reference rows)")
     if all_fp32 is not None:
         mf.close()
 

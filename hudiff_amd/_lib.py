@@ -34,7 +34,8 @@ EXPORTS = [
 OPTIONS = {n: i for i, n in enumerate((
     "lanes", "lane_min_rows", "split_min_rows", "big_min_rows", "lnsync_level", "tail_form", "tail_max_rows", "small_grid", "tiny_grid",
     "loader_waves", "tiny_stages", "small_stages", "small_stages3_max_grid", "attn_qsplit_max_grid", "attn_waves", "loop_graph",
-    "prune_value_via_rows", "split_tile", "gemm_small_tiles", "store_nt", "split_layer_mask", "split_attn", "fused_attn", "fused_attn_min_grid"))}
+    "prune_value_via_rows", "split_tile", "gemm_small_tiles", "store_nt", "split_layer_mask", "split_attn", "fused_attn", "fused_attn_min_grid",
+    "bn_chain", "bn_chain_min_tiles"))}
 
 
 class HdConfig(C.Structure):

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhudiff_hip.so")
 SOURCES = [os.path.join(CSRC, "hd_api.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "hd_kernels.hip.h"), os.path.join(CSRC, "hd_tail_fused.hip.h"),
-                  os.path.join(CSRC, "hd_attn_fused.hip.h"),
+                  os.path.join(CSRC, "hd_attn_fused.hip.h"), os.path.join(CSRC, "hd_chain.hip.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hudiff_hip.h")]
 
 
@@ -33,7 +33,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", "-Wno-unused-value", *os.environ.get("HUDIFF_CXXFLAGS", "").split(), *SOURCES, "-o", LIB]
+           "-Wno-unused-result", "-Wno-unused-value",
+           # (hd_chain.hip.h: its fully unrolled LayerNorm / split passes exceed LLVM's default 16 K-instruction bound for `#pragma unroll`)
+           "-mllvm", "-pragma-unroll-threshold=200000", *os.environ.get("HUDIFF_CXXFLAGS", "").split(), *SOURCES, "-o", LIB]
     if verbose:
         print("[hudiff_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -9,6 +9,7 @@
 #include "hd_kernels.hip.h"
 #include "hd_tail_fused.hip.h"
 #include "hd_attn_fused.hip.h"
+#include "hd_chain.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -65,6 +66,7 @@ struct ByteNetW {   // one ByteNet block, both segments packed back to back
     const float *ln1_g, *ln1_b, *w1, *b1, *ln2_g, *ln2_b, *wc, *bc, *ln3_g, *ln3_b, *w3, *b3;
     int dil;
     X3W wcx, w1x, w3x;
+    X3W w3px;           // w3 with the k order of hd_chain.hip.h's phase B (permuted inside every group of 16)
 };
 struct AttLayerW { const float *wqkv, *bqkv, *wo, *bo; X3W wqkvx, wox; };
 struct AttBlockW {
@@ -131,6 +133,14 @@ static const OptDef OPTS[HD_OPT_COUNT] = {
     // one workgroup per (sequence, head group): with fewer than ~half the CUs busy the two-launch form's finer tiles win (round 5 sweep,
     // profiles/r05: antibodies B = 8 30.9 vs 34.1 sequences/s, B = 16 52.1 vs 51.4, B = 64 89.0 vs 85.1; nanobodies B = 16 129 vs 138, B = 64 322 vs 293)
     {HD_OPT_FUSED_ATTN_MIN_GRID, "HUDIFF_FUSED_ATTN_MIN_GRID", 128, 0, OPT_BIG, {}, 0, false},
+    // round 6: the row-owner chain kernel (hd_chain.hip.h) for ByteNet stacks of the split route: bit 0 Dual / NanoConv, bit 1 token encoder.
+    // OFF by default: correct (tests/test_gpu_chain.py) and n + 1 launches per stack instead of 3 n + 1, but measured no faster than the
+    // three gemm_x3_k launches per block at 256 antibodies (dual stack 1 058 vs 920 us per block, sample 104.5 vs 108.0 sequences/s) nor
+    // at 256 nanobodies (488 vs 486): one wave per SIMD has nobody to cover its DMA issue and LDS latency (NOTES.md E, profiles/r06)
+    {HD_OPT_BN_CHAIN, "HUDIFF_BN_CHAIN", 0, 0, 3, {}, 0, true},
+    // fewest workgroup tiles (128 rows; 256 for the token encoder) of a launch, over all lanes, for which the chain kernel is taken: one
+    // workgroup owns a CU, so a launch that leaves most CUs empty keeps the gemm_x3_k tiles
+    {HD_OPT_BN_CHAIN_MIN_TILES, "HUDIFF_BN_CHAIN_MIN_TILES", 128, 0, OPT_BIG, {}, 0, false},
 };
 static bool opt_legal(const OptDef& d, int64_t v) {
     if (v < d.lo || v > d.hi) return false;
@@ -504,7 +514,9 @@ struct X3Packer {
     std::vector<uint16_t> buf;
     static uint16_t h16(float x) { _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
     static float f16(float x) { return (float)(_Float16)x; }
-    X3Off add(const std::vector<float>& w, int nseg, int Ktot, int N) {
+    // kperm: inside every group of 16 k the image holds k in the order {0-3, 8-11, 4-7, 12-15} -- the order in which a lane of hd_chain.hip.h's
+    // phase B holds the channels of its accumulators (MFMA output rows 8 q + 4 (lane >> 5) + e), which it feeds back as the B operand
+    X3Off add(const std::vector<float>& w, int nseg, int Ktot, int N, bool kperm = false) {
         X3Off o;
         if (Ktot % X3_BK || N % X3_BN || w.size() != (size_t)nseg * Ktot * N) return o;
         float mx = 0.f;
@@ -529,7 +541,9 @@ struct X3Packer {
                     uint16_t* t = dst + ((size_t)a * kt + b) * X3_TILE_HALFS;
                     for (int n = 0; n < X3_BN; ++n)
                         for (int k = 0; k < X3_BK; ++k) {
-                            const float v = ws[(size_t)(b * X3_BK + k) * N + a * X3_BN + n] * sc;
+                            static const int src16[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
+                            const int ks = kperm ? ((k & ~15) | src16[k & 15]) : k;          // image position k holds source row ks
+                            const float v = ws[(size_t)(b * X3_BK + ks) * N + a * X3_BN + n] * sc;
                             const float hi = f16(v);
                             const int pos = n * X3_BK + ((((k >> 3) ^ ((n >> 2) & 3)) << 3) | (k & 7));
                             t[pos] = h16(hi);
@@ -638,11 +652,12 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
         for (auto& s : segn) pf.push_back(convp + s + "." + std::to_string(n) + ".");
         conv_off.push_back(pack_bytenet(ld, pk, pf, D, Dh, ks));
     }
-    struct BnX { X3Off wc, w1, w3; };
+    struct BnX { X3Off wc, w1, w3, w3p; };
     std::vector<BnX> enc_x, conv_x;
     auto bnx = [&](ByteNetOff& o, int din, int dhh) {
         BnX x;
-        if (xp_bn) { x.wc = xp_bn->add(o.wc_copy, m->nseg, ks * dhh, dhh); x.w1 = xp_bn->add(o.w1_copy, m->nseg, din, dhh); x.w3 = xp_bn->add(o.w3_copy, m->nseg, dhh, din); }
+        if (xp_bn) { x.wc = xp_bn->add(o.wc_copy, m->nseg, ks * dhh, dhh); x.w1 = xp_bn->add(o.w1_copy, m->nseg, din, dhh); x.w3 = xp_bn->add(o.w3_copy, m->nseg, dhh, din);
+                     if (m->opt[HD_OPT_BN_CHAIN]) x.w3p = xp_bn->add(o.w3_copy, m->nseg, dhh, din, /*kperm=*/true); }
         for (auto* v : {&o.wc_copy, &o.w1_copy, &o.w3_copy}) { v->clear(); v->shrink_to_fit(); }
         return x;
     };
@@ -755,11 +770,11 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     };
     for (int n = 0; n < c.n_encoder_layers; ++n) {
         m->enc.push_back(mk(enc_off[n], n));
-        m->enc.back().wcx = mkx(enc_x[n].wc); m->enc.back().w1x = mkx(enc_x[n].w1); m->enc.back().w3x = mkx(enc_x[n].w3);
+        m->enc.back().wcx = mkx(enc_x[n].wc); m->enc.back().w1x = mkx(enc_x[n].w1); m->enc.back().w3x = mkx(enc_x[n].w3); m->enc.back().w3px = mkx(enc_x[n].w3p);
     }
     for (int n = 0; n < c.dual_layers; ++n) {
         m->conv.push_back(mk(conv_off[n], n));
-        m->conv.back().wcx = mkx(conv_x[n].wc); m->conv.back().w1x = mkx(conv_x[n].w1); m->conv.back().w3x = mkx(conv_x[n].w3);
+        m->conv.back().wcx = mkx(conv_x[n].wc); m->conv.back().w1x = mkx(conv_x[n].w1); m->conv.back().w3x = mkx(conv_x[n].w3); m->conv.back().w3px = mkx(conv_x[n].w3p);
     }
     for (auto& o : att_off) {
         AttBlockW w;
@@ -797,6 +812,7 @@ extern "C" HdStatus hd_finalize(HdModel* m) {
     HIP_TRY(hipFuncSetAttribute((const void*)attn_x3_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)qkv_attn_x3_k<19, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
     HIP_TRY(hipFuncSetAttribute((const void*)qkv_attn_x3_k<10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, att_cap));
+    if (m->x3 && m->opt[HD_OPT_BN_CHAIN]) HIP_TRY(bn_chain_prepare());
     static_assert(lds_safe_request(AxGeom<19>::SMEM, ATT_THREADS) <= LDS_PER_CU && lds_safe_request(AxGeom<10>::SMEM, ATT_THREADS) <= LDS_PER_CU, "LDS co-residency rule");
     HIP_TRY(hipStreamSynchronize(cur(m).stream));
     m->host.clear();
@@ -1393,6 +1409,69 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
     launch_gemm(m, p, false, false);
 }
 
+// ---- ByteNet stack on the row-owner chain kernel (hd_chain.hip.h; round 6) -----------------------------------------------------------
+// A stack of n blocks as n + 1 launches:  C(0) | A B(0) C(1) | ... | A B(n - 1).  x0 [rows, ld0] fp32 with its (mean, rstd) in ws.ST;
+// block k reads its input from x0 (k = 0) or `out`, writes `out` (the last block: `last_out`, row stride `last_ld`, + `extra`).  h1 of
+// consecutive blocks alternates between ha / hb (phase A of a launch reads the buffer phase C of the previous launch wrote, neighbours'
+// rows included, while this launch's phase C writes the other one).  last_split: X16 copy of the last block's output (attention operand).
+static bool bn_chain_use(const HdModel* m, const Segs& sg, const std::vector<ByteNetW>& blocks, int din, int dh, int act, int stack_bit) {
+    if (!(m->opt[HD_OPT_BN_CHAIN] & stack_bit) || blocks.empty() || !bn_chain_supported(dh, din, act) || m->cfg.kernel_size != 7) return false;
+    for (const ByteNetW& w : blocks)
+        if (!(x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && w.w3px.w)) return false;
+    const int tr = bn_chain_tile_rows(dh);
+    long tiles = ((long)sg.B * sg.len[0] + tr - 1) / tr + (sg.nseg > 1 ? ((long)sg.B * sg.len[1] + tr - 1) / tr : 0);
+    return tiles * (m->in_session ? m->nlanes : 1) >= m->opt[HD_OPT_BN_CHAIN_MIN_TILES];
+}
+static void bytenet_stack_chain(HdModel* m, const Segs& sg, const std::vector<ByteNetW>& blocks, int din, int dh, int act,
+                                const float* x0, int ld0, float* out, float* last_out, int last_ld, float* ha, float* hb,
+                                int drop_mode, float drop_p, uint32_t site0, const uint8_t* masks, size_t mask_stride,
+                                const float* extra, int lde, float* last_split) {
+    hipStream_t st = cur(m).stream;
+    Workspace& ws = cur(m).ws;
+    const long rows = sg.rows();
+    const int n = (int)blocks.size();
+    auto base = [&]() {
+        ChainP p{};
+        p.sg = sg; p.rs = cur(m).rs; p.act = act;
+        return p;
+    };
+    auto set_c = [&](ChainP& p, const ByteNetW& w, float* h1out) {      // phase C: open block `w`
+        p.W1 = w.w1x.w; p.w1_seg = w.w1x.seg_stride; p.sc_1 = w.w1x.acc_scale;
+        p.b1 = w.b1; p.g1 = w.ln1_g; p.be1 = w.ln1_b; p.g2 = w.ln2_g; p.be2 = w.ln2_b; p.H1out = h1out;
+    };
+    {   // C(0)
+        ChainP p = base();
+        p.phases = 2;
+        p.Yin = x0; p.ldyin = ld0; p.yin_bytes = (uint32_t)(rows * ld0 * 4); p.STin = ws.ST;
+        set_c(p, blocks[0], ha);
+        launch_bn_chain(p, dh, din, false, st);
+    }
+    for (int k = 0; k < n; ++k) {
+        const ByteNetW& w = blocks[k];
+        const bool last = k + 1 == n;
+        ChainP p = base();
+        p.phases = last ? 1 : 3;
+        p.H1 = (k & 1) ? hb : ha; p.h1_bytes = (uint32_t)(rows * dh * 4); p.taps = m->cfg.kernel_size; p.dil = w.dil;
+        p.Wc = w.wcx.w; p.wc_seg = w.wcx.seg_stride; p.sc_c = w.wcx.acc_scale; p.bc = w.bc; p.g3 = w.ln3_g; p.be3 = w.ln3_b;
+        p.W3 = w.w3px.w; p.w3_seg = w.w3px.seg_stride; p.sc_3 = w.w3px.acc_scale; p.b3 = w.b3;
+        p.X = k == 0 ? x0 : out; p.ldx = k == 0 ? ld0 : din; p.x_bytes = (uint32_t)(rows * p.ldx * 4);
+        p.Y = last ? last_out : out; p.ldy = last ? last_ld : din;
+        p.YX = last ? last_split : nullptr;
+        p.extra = last ? extra : nullptr; p.lde = lde;
+        p.drop_mode = DROP_NONE;
+        if (drop_mode != DROP_NONE && drop_p > 0.f) {
+            const double t = floor((double)drop_p * 4294967296.0);
+            p.drop_mode = drop_mode;
+            p.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+            p.drop_scale = (float)(1.0 / (1.0 - (double)drop_p));
+            p.drop_site = site0 + (uint32_t)k;
+            p.drop_mask = masks ? masks + (size_t)k * mask_stride : nullptr;
+        }
+        if (!last) set_c(p, blocks[k + 1], (k & 1) ? ha : hb);
+        launch_bn_chain(p, dh, din, p.drop_mode == DROP_INJECT, st);
+    }
+}
+
 // One denoiser forward up to the last attention block; result rows in ws.Y.
 static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const uint8_t* enc_masks, const uint8_t* conv_masks,
                              bool prune_last = false) {
@@ -1402,7 +1481,11 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
     const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
     hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
-    for (int n = 0; n < c.n_encoder_layers; ++n) {
+    const bool enc_chain = bn_chain_use(m, sg, m->enc, d, dh, c.enc_act, 2) && ws.S1;
+    if (enc_chain)      // (ws.ST: the embedding rows' statistics, written by embed_tokens_k)
+        bytenet_stack_chain(m, sg, m->enc, d, dh, c.enc_act, ws.X, d, ws.X, ws.FEAT, D, ws.H1, ws.H2, m->p_enc > 0.f ? drop_mode : DROP_NONE, m->p_enc, 0u,
+                            enc_masks, enc_stride, ws.EXTRA, d, nullptr);
+    for (int n = 0; n < c.n_encoder_layers && !enc_chain; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_enc > 0.f) { dr.mode = drop_mode; dr.p = m->p_enc; dr.site = (uint32_t)n; dr.mask = enc_masks ? enc_masks + n * enc_stride : nullptr; }
         const bool last = n == c.n_encoder_layers - 1;
@@ -1414,7 +1497,13 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     }
     if (m->debug_stop_after == 1) return HD_OK;
     const bool ax3 = att_x3(m, sg);
-    for (int n = 0; n < c.dual_layers; ++n) {
+    const bool conv_chain = bn_chain_use(m, sg, m->conv, D, Dh, c.conv_act, 1) && ws.S1;
+    if (conv_chain) {
+        launch_stats(m, ws.FEAT, D, D, rows, st);       // FEAT's static two thirds were not written by a GEMM: one statistics pass
+        bytenet_stack_chain(m, sg, m->conv, D, Dh, c.conv_act, ws.FEAT, D, ws.Y, ws.Y, D, ws.G1, ws.G2, m->p_conv > 0.f ? drop_mode : DROP_NONE, m->p_conv, 64u,
+                            conv_masks, conv_stride, nullptr, 0, ax3 ? ws.YX : nullptr);
+    }
+    for (int n = 0; n < c.dual_layers && !conv_chain; ++n) {
         Drop dr;
         if (drop_mode != DROP_NONE && m->p_conv > 0.f) { dr.mode = drop_mode; dr.p = m->p_conv; dr.site = 64u + (uint32_t)n; dr.mask = conv_masks ? conv_masks + n * conv_stride : nullptr; }
         // block 0 reads FEAT, whose static two thirds were not written by a GEMM: one explicit statistics pass

@@ -251,7 +251,12 @@ typedef enum HdOption {
                                                                              (sequence, head group), K / V never leave the CU); 0 = projection GEMM + attention core    */
     HD_OPT_FUSED_ATTN_MIN_GRID = 23,/* HUDIFF_FUSED_ATTN_MIN_GRID 128 [0, ..] fewest (sequence, head group) workgroups -- over all lanes -- for which the fused
                                                                              form is taken (below, the two-launch form's finer tiles fill the chip better)        */
-    HD_OPT_COUNT = 24
+    HD_OPT_BN_CHAIN = 24,           /* HUDIFF_BN_CHAIN         0     [0, 3]   [create] split route: ByteNet stacks on the row-owner chain kernel (a wave owns whole rows
+                                                                           through conv -> LN -> PFF3 -> residual -> LN -> PFF1 -> LN; n + 1 launches per stack): bit 0
+                                                                           Dual / NanoConv, bit 1 token encoder; 0 (default: measured no faster, NOTES.md E) = three
+                                                                           gemm_x3_k launches per block                                                                        */
+    HD_OPT_BN_CHAIN_MIN_TILES = 25, /* HUDIFF_BN_CHAIN_MIN_TILES 128 [0, ..]  fewest workgroup tiles (128 rows; token encoder 256), over all lanes, that take the chain kernel */
+    HD_OPT_COUNT = 26
 } HdOption;
 HdStatus hd_set_option(HdModel* m, int32_t option, int64_t value);
 HdStatus hd_get_option(HdModel* m, int32_t option, int64_t* value);

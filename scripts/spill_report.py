@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "hudiff_amd", "csrc", "hd_api.hip")
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Rpass-analysis=kernel-resource-usage",
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-mllvm", "-pragma-unroll-threshold=200000", "-Rpass-analysis=kernel-resource-usage",
                     src, "-o", "/tmp/hd_api_spill.o"], capture_output=True, text=True)
 txt = r.stderr + r.stdout
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
