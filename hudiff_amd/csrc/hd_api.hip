@@ -1446,6 +1446,21 @@ static void bytenet_stack_chain(HdModel* m, const Segs& sg, const std::vector<By
         set_c(p, blocks[0], ha);
         launch_bn_chain(p, dh, din, false, st);
     }
+#ifdef HD_CHAIN_EXPERIMENT
+    static const int chain_exp = [] { const char* e = getenv("HUDIFF_CHAIN_EXP"); return e ? atoi(e) : 0; }();      // 1: phase A alone per block (bn_chain_k PH = 4), 2: bn_pair_a_k -- TIMING ONLY
+    if (chain_exp && dh >= 256) {
+        for (int k = 0; k < n; ++k) {
+            const ByteNetW& w = blocks[k];
+            ChainP p = base();
+            p.phases = 4;
+            p.H1 = ha; p.h1_bytes = (uint32_t)(rows * dh * 4); p.taps = m->cfg.kernel_size; p.dil = w.dil;
+            p.Wc = w.wcx.w; p.wc_seg = w.wcx.seg_stride; p.sc_c = w.wcx.acc_scale; p.bc = w.bc; p.g3 = w.ln3_g; p.be3 = w.ln3_b;
+            p.H2dbg = hb;
+            if (chain_exp == 2) launch_bn_pair_a(p, dh, st); else launch_bn_chain(p, dh, din, false, st);
+        }
+        return;
+    }
+#endif
     for (int k = 0; k < n; ++k) {
         const ByteNetW& w = blocks[k];
         const bool last = k + 1 == n;

@@ -663,6 +663,172 @@ __global__ void __launch_bounds__(CH_THREADS, 1) bn_chain_k(const ChainP p) {
     }
 }
 
+#ifdef HD_CHAIN_EXPERIMENT
+// ---- experiment (round 6, NOTES.md E): phase A with TWO waves per SIMD -- eight waves per workgroup, a PAIR of waves owns 32 rows and each
+// wave of the pair half of the hidden channels (CT / 2 tiles: 96 accumulator registers at 384 channels), so that a wave stalled in the issue
+// of a DMA piece or waiting for a fragment has a neighbour that feeds the matrix pipe.  Probe libraries only (-DHD_CHAIN_EXPERIMENT,
+// HUDIFF_CHAIN_EXP=2 launches it in place of every block: timing, not results).
+template <int CT, int ACT>
+__global__ void __launch_bounds__(512, 1) bn_pair_a_k(const ChainP p) {
+    constexpr int DH = 32 * CT, NTH = CT / 4, STAGE = CT * 4096, CTW = CT / 2, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char chs[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 1, hf = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    int bx = blockIdx.x, seg = 0;
+    if (bx >= p.tiles) return;
+    if (p.sg.nseg > 1 && bx >= p.tiles0) { seg = 1; bx -= p.tiles0; }
+    const int Lc = p.sg.len[seg], seg_rows = p.sg.B * Lc, rbase = p.sg.base[seg];
+    const int m0 = bx * 128 + grp * 32;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    constexpr uint32_t BUF_OOB = 0x80000000u;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    using std::integral_constant;
+    const int lrow = m0 + l31; const bool rok = lrow < seg_rows;
+    const int fsw = (lane >> 2) & 3;
+    const int woff0 = l31 * 64 + (((0 + kh) ^ fsw) << 4), woff1 = l31 * 64 + (((2 + kh) ^ fsw) << 4);
+    f32x16 acc[CTW];
+    constexpr int WPIECES = NTH * 16 / NW;
+    const uint16_t* Wc = p.Wc + (long)seg * p.wc_seg;
+    const int nkt = p.taps * CT, half = (p.taps - 1) / 2;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wc), 0, NTH * nkt * X3_TILE_BYTES, 0x00020000);
+    auto dma_w_tile = [&](int q, int st) {
+        char* dst = chs + st * STAGE;
+#pragma unroll
+        for (int j = 0; j < WPIECES; ++j) {
+            const int piece = NW * j + wave;
+            const int nt = piece >> 4, within = piece & 15;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_vp)(dst + piece * 1024), 16, (int)((nt * nkt) * X3_TILE_BYTES + within * 1024 + lane * 16), q * X3_TILE_BYTES, 0, 0);
+        }
+    };
+    auto mma_step = [&](const char* Wt, int wo, const f16x8 xh, const f16x8 xl) {
+        f16x8 wh[2][2], wl[2][2];
+        auto ldw = [&](int tp, int b) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = hf * CTW + 2 * tp + u;
+                const char* a = Wt + (t >> 2) * 16384 + (t & 3) * 2048 + wo;
+                wh[b][u] = *reinterpret_cast<const f16x8*>(a);
+                wl[b][u] = *reinterpret_cast<const f16x8*>(a + 8192);
+            }
+        };
+        ldw(0, 0);
+#pragma unroll
+        for (int tp = 0; tp < CTW / 2; ++tp) {
+            const int b = tp & 1;
+            if (tp + 1 < CTW / 2) ldw(tp + 1, b ^ 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[2 * tp + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][u], xl, acc[2 * tp + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[2 * tp + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b][u], xh, acc[2 * tp + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[2 * tp + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b][u], xh, acc[2 * tp + u], 0, 0, 0);
+        }
+    };
+    auto vm_wait = [&](auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);
+    };
+    const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.H1), 0, (int)p.h1_bytes, 0x00020000);
+    const int pos = rok ? lrow % Lc : -(1 << 24);
+    struct XT { f16x8 h[2], l[2]; };
+    auto ldx = [&](int q, XT& x) {
+        const int tap = q / CT, kt = q - tap * CT;
+        const int shift = (tap - half) * p.dil;
+        const uint32_t vo = (unsigned)(pos + shift) < (unsigned)Lc ? (uint32_t)(rbase + lrow + shift) * (uint32_t)(DH * 4) + (uint32_t)kh * 16u : BUF_OOB;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            x.h[s2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(h_rs, (int)vo, (2 * kt + s2) * 64, 0));
+            x.l[s2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(h_rs, (int)vo, (2 * kt + s2) * 64 + 32, 0));
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    XT xa, xb;
+    dma_w_tile(0, 0);
+    ldx(0, xa);
+    dma_w_tile(1, 1);
+    int st = 0;
+    auto body = [&](int q, XT& xc, XT& xn) {
+        vm_wait(integral_constant<int, WPIECES>{});
+        lds_barrier();
+        const int st2 = st == 0 ? 2 : st - 1;
+        ldx(min(q + 1, nkt - 1), xn);
+        dma_w_tile(min(q + 2, nkt - 1), st2);
+        const char* Wt = chs + st * STAGE;
+        mma_step(Wt, woff0, xc.h[0], xc.l[0]);
+        mma_step(Wt, woff1, xc.h[1], xc.l[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st == 2 ? 0 : st + 1;
+    };
+    for (int q = 0; q < nkt; q += 2) { body(q, xa, xb); body(q + 1, xb, xa); }
+    // finish: scale + bias, LayerNorm over the pair's DH channels (each wave its half: (mean, M2) of the halves merged through LDS), activation, split, X16 rows out
+    vm_wait(integral_constant<int, 0>{});
+    lds_barrier();
+    float* fin = reinterpret_cast<float*>(chs);
+    for (int i = tid; i < DH; i += 512) { fin[i] = p.bc[seg * DH + i]; fin[DH + i] = p.g3[seg * DH + i]; fin[2 * DH + i] = p.be3[seg * DH + i]; }
+    float2* xch = reinterpret_cast<float2*>(chs + 3 * DH * 4);          // [wave][32 rows] (mean, M2) of a wave's channel half
+    lds_barrier();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(fin + 32 * (hf * CTW + t) + 8 * q + 4 * kh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float v = acc[t][4 * q + e] * p.sc_c + b4[e]; acc[t][4 * q + e] = v; s += v; }
+        }
+    s += __shfl_xor(s, 32);
+    const float mh = s * (1.0f / (float)(DH / 2));
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[t][r] - mh; m2 += d * d; }
+    m2 += __shfl_xor(m2, 32);
+    if (kh == 0) xch[wave * 32 + l31] = make_float2(mh, m2);
+    lds_barrier();
+    const float2 o = xch[(wave ^ 1) * 32 + l31];
+    const float mean = 0.5f * (mh + o.x), dlt = mh - o.x;
+    const float rstd = 1.0f / sqrtf((m2 + o.y + dlt * dlt * (0.25f * (float)DH)) * (1.0f / (float)DH) + 1e-5f);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(p.H2dbg, 0, 0x7FFFFFFF, 0x00020000);
+    const uint32_t rb = rok ? (uint32_t)(rbase + lrow) * (uint32_t)(DH * 4) : BUF_OOB;
+    float vmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        const int tg = hf * CTW + t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(fin + DH + 32 * tg + 8 * q + 4 * kh);
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(fin + 2 * DH + 32 * tg + 8 * q + 4 * kh);
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = act_f((acc[t][4 * q + e] - mean) * rstd * g4[e] + e4[e], ACT);
+            if (rok) vmax = absmax4(vmax, w);
+            f16x4 h4, l4;
+            split4(w, h4, l4);
+            const int c = 32 * tg + 8 * q + 4 * kh;
+            const uint32_t oo = rb == BUF_OOB ? BUF_OOB : rb + (uint32_t)(x16_hi(c) * 2);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), d_rs, (int)oo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), d_rs, (int)(oo == BUF_OOB ? BUF_OOB : oo + (uint32_t)X16_LO * 2u), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    raise_range_flag(p.rs, vmax);
+}
+static void launch_bn_pair_a(ChainP p, int DH, hipStream_t st) {
+    const int rows0 = p.sg.B * p.sg.len[0], rows1 = p.sg.nseg > 1 ? p.sg.B * p.sg.len[1] : 0;
+    p.tiles0 = (rows0 + 127) / 128; p.tiles = p.tiles0 + (rows1 + 127) / 128;
+    static bool prep = false;
+    if (!prep) { prep = true; hipFuncSetAttribute((const void*)bn_pair_a_k<12, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 12 * 4096 + 8192);
+                 hipFuncSetAttribute((const void*)bn_pair_a_k<8, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 4096 + 8192); }
+    if (DH == 384) hipLaunchKernelGGL((bn_pair_a_k<12, ACT_RELU>), dim3(p.tiles), dim3(512), 3 * 12 * 4096 + 8192, st, p);
+    else if (DH == 256) hipLaunchKernelGGL((bn_pair_a_k<8, ACT_GELU>), dim3(p.tiles), dim3(512), 3 * 8 * 4096 + 8192, st, p);
+}
+#endif
+
 // ---- host side: instantiations and launcher ----------------------------------------------------------------------------------------
 // (CT, DT) = (hidden width / 32, block width / 32): 12 x 24 DualConv (768 / 384), 8 x 16 NanoConv (512 / 256), 4 x 8 token encoder (256 / 128)
 static bool bn_chain_supported(int DH, int D, int act) {
