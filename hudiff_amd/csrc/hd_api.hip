@@ -1414,7 +1414,9 @@ static void pruned_tail(HdModel* m, const Segs& sg, const AttBlockW& w) {
 // block k reads its input from x0 (k = 0) or `out`, writes `out` (the last block: `last_out`, row stride `last_ld`, + `extra`).  h1 of
 // consecutive blocks alternates between ha / hb (phase A of a launch reads the buffer phase C of the previous launch wrote, neighbours'
 // rows included, while this launch's phase C writes the other one).  last_split: X16 copy of the last block's output (attention operand).
-static bool bn_chain_use(const HdModel* m, const Segs& sg, const std::vector<ByteNetW>& blocks, int din, int dh, int act, int stack_bit) {
+static bool bn_chain_use(const HdModel* m, const Segs& sg, const std::vector<ByteNetW>& blocks, int din, int dh, int act, int stack_bit, int drop_mode, bool last_operand) {
+    // (injected keep-masks -- parity tests -- and a last block without its optional operand keep the gemm_x3_k path: no instantiation for them)
+    if (drop_mode == DROP_INJECT || !last_operand) return false;
     if (!(m->opt[HD_OPT_BN_CHAIN] & stack_bit) || blocks.empty() || !bn_chain_supported(dh, din, act) || m->cfg.kernel_size != 7) return false;
     for (const ByteNetW& w : blocks)
         if (!(x3_use(m, sg, w.w1x) && x3_use(m, sg, w.wcx) && w.w3px.w)) return false;
@@ -1444,7 +1446,7 @@ static void bytenet_stack_chain(HdModel* m, const Segs& sg, const std::vector<By
         p.phases = 2;
         p.Yin = x0; p.ldyin = ld0; p.yin_bytes = (uint32_t)(rows * ld0 * 4); p.STin = ws.ST;
         set_c(p, blocks[0], ha);
-        launch_bn_chain(p, dh, din, false, st);
+        launch_bn_chain(p, dh, din, st);
     }
 #ifdef HD_CHAIN_EXPERIMENT
     static const int chain_exp = [] { const char* e = getenv("HUDIFF_CHAIN_EXP"); return e ? atoi(e) : 0; }();      // 1: phase A alone per block (bn_chain_k PH = 4), 2: bn_pair_a_k -- TIMING ONLY
@@ -1456,7 +1458,7 @@ static void bytenet_stack_chain(HdModel* m, const Segs& sg, const std::vector<By
             p.H1 = ha; p.h1_bytes = (uint32_t)(rows * dh * 4); p.taps = m->cfg.kernel_size; p.dil = w.dil;
             p.Wc = w.wcx.w; p.wc_seg = w.wcx.seg_stride; p.sc_c = w.wcx.acc_scale; p.bc = w.bc; p.g3 = w.ln3_g; p.be3 = w.ln3_b;
             p.H2dbg = hb;
-            if (chain_exp == 2) launch_bn_pair_a(p, dh, st); else launch_bn_chain(p, dh, din, false, st);
+            if (chain_exp == 2) launch_bn_pair_a(p, dh, st); else launch_bn_chain(p, dh, din, st);
         }
         return;
     }
@@ -1483,7 +1485,7 @@ static void bytenet_stack_chain(HdModel* m, const Segs& sg, const std::vector<By
             p.drop_mask = masks ? masks + (size_t)k * mask_stride : nullptr;
         }
         if (!last) set_c(p, blocks[k + 1], (k & 1) ? ha : hb);
-        launch_bn_chain(p, dh, din, p.drop_mode == DROP_INJECT, st);
+        launch_bn_chain(p, dh, din, st);
     }
 }
 
@@ -1496,7 +1498,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     const int d = m->d, dh = m->dh, D = m->D, Dh = m->Dh, rows = sg.rows();
     const size_t enc_stride = (size_t)sg.B * m->L * d, conv_stride = (size_t)sg.B * m->L * D;
     hipLaunchKernelGGL(embed_tokens_k, dim3((rows + 3) / 4), dim3(256), 0, st, ws.tokens, m->emb, m->emb_stats, d, ws.X, ws.ST, sg);
-    const bool enc_chain = bn_chain_use(m, sg, m->enc, d, dh, c.enc_act, 2) && ws.S1;
+    const bool enc_chain = bn_chain_use(m, sg, m->enc, d, dh, c.enc_act, 2, drop_mode, ws.EXTRA != nullptr) && ws.S1;
     if (enc_chain)      // (ws.ST: the embedding rows' statistics, written by embed_tokens_k)
         bytenet_stack_chain(m, sg, m->enc, d, dh, c.enc_act, ws.X, d, ws.X, ws.FEAT, D, ws.H1, ws.H2, m->p_enc > 0.f ? drop_mode : DROP_NONE, m->p_enc, 0u,
                             enc_masks, enc_stride, ws.EXTRA, d, nullptr);
@@ -1512,7 +1514,7 @@ static HdStatus forward_body(HdModel* m, const Segs& sg, int drop_mode, const ui
     }
     if (m->debug_stop_after == 1) return HD_OK;
     const bool ax3 = att_x3(m, sg);
-    const bool conv_chain = bn_chain_use(m, sg, m->conv, D, Dh, c.conv_act, 1) && ws.S1;
+    const bool conv_chain = bn_chain_use(m, sg, m->conv, D, Dh, c.conv_act, 1, drop_mode, ax3 && ws.YX) && ws.S1;
     if (conv_chain) {
         launch_stats(m, ws.FEAT, D, D, rows, st);       // FEAT's static two thirds were not written by a GEMM: one statistics pass
         bytenet_stack_chain(m, sg, m->conv, D, Dh, c.conv_act, ws.FEAT, D, ws.Y, ws.Y, D, ws.G1, ws.G2, m->p_conv > 0.f ? drop_mode : DROP_NONE, m->p_conv, 64u,

@@ -35,7 +35,7 @@ def _models(hip, kind, dropout=None):
 @pytest.mark.parametrize("kind,B", [("ab", 48), ("nb", 96)])
 def test_chain_kernel_matches_the_per_gemm_launches(hip, kind, B):
     """Token encoder, Dual / NanoConv stack and the X16 copy handed to the attention: stage by stage and at the logits; generated
-    dropout (the same keep decisions: the hash is keyed by (row, slot, column)) and injected keep-masks; tokens of a short sample."""
+    dropout (the same keep decisions: the hash is keyed by (row, slot, column)); tokens of a short sample."""
     from hudiff_amd import evalsets as E
     cfg, old, new = _models(hip, kind)
     try:
@@ -54,8 +54,9 @@ def test_chain_kernel_matches_the_per_gemm_launches(hip, kind, B):
         L, d, D = cfg["max_len"], cfg["d_model"], cfg["sum_d_model"]
         em = (rng.random((cfg["n_encoder_layers"], B, L, d)) >= cfg["dropout"]).astype(np.uint8)
         cm = (rng.random((cfg["dual_layers"], B, L, D)) >= 0.5).astype(np.uint8)
+        # (injected keep-masks keep the gemm_x3_k launches on both handles -- the chain kernel is instantiated for generated dropout only: the same bits)
         a, c = old(*args, dropout="inject", enc_masks=em, conv_masks=cm), new(*args, dropout="inject", enc_masks=em, conv_masks=cm)
-        assert float(np.abs(a - c).max()) < 3e-4
+        assert np.array_equal(a, c)
         T6 = np.minimum(b["T"], 6)
         assert np.array_equal(old.sample(*args, b["order"], T6, seed=3, row0=0), new.sample(*args, b["order"], T6, seed=3, row0=0))
         info = new.precision_info()
