@@ -6,22 +6,27 @@
 // (ln_sync) and which passed h1, h2, S = act(LN(out)) and a second copy of every N = 768 output through HBM: 0.16-0.45 of the split
 // MFMA peak, bound by the L2 -> LDS operand path and by epilogues nothing overlapped (NOTES.md D).
 //
-// Here a WAVE owns 64 whole rows through everything that is row-local, and only the 7-tap convolution -- which needs neighbouring rows
+// Here a WAVE owns 32 whole rows (64 in the 128-wide token encoder) through everything that is row-local, and only the 7-tap convolution -- which needs neighbouring rows
 // -- is a launch boundary:
-//   phase A  h2^T[DH, 64] = Wc^T . shift_tap(h1)^T     the k = 7 dilated conv as 7 row-shifted tap GEMMs, computed TRANSPOSED: the weights
+//   phase A  h2^T[DH, rows] = Wc^T . shift_tap(h1)^T     the k = 7 dilated conv as 7 row-shifted tap GEMMs, computed TRANSPOSED: the weights
 //            are the MFMA's A operand (from LDS, shared by the workgroup's four waves), the wave's own activation rows its B operand
 //            (straight from global memory into registers, zero padding at the chain ends from the buffer descriptor's range check).  A lane
 //            then holds 16 channels of ONE row per 32 x 32 tile and all DH channels of its row over the CT tiles: LayerNorm 3 is a
 //            lane-local reduction plus one exchange with lane ^ 32 -- no partials, no meeting, no second pass.
-//   phase B  out^T[32-channel chunk, 64] = W3^T . act(LN3(h2))^T + b3 + x, dropout, (+ extra): act(LN3(h2)) never leaves the registers --
+//   phase B  out^T[32-channel chunk, rows] = W3^T . act(LN3(h2))^T + b3 + x, dropout, (+ extra): act(LN3(h2)) never leaves the registers --
 //            split (hi, lo) in place, it IS the B operand (the k order of W3's image is permuted at hd_finalize to the order the
 //            accumulators hold channels in).  Per chunk: fp32 rows out (one copy), LayerNorm statistics of the finished row accumulated
 //            on the way (Chan et al.), residual rows staged by LDS DMA.
-//   phase C  h1'^T[DH, 64] = W1'^T . act(LN1'(out))^T of the NEXT block: the wave reads back the rows it just wrote (past the L1),
+//   phase C  h1'^T[DH, rows] = W1'^T . act(LN1'(out))^T of the NEXT block: the wave reads back the rows it just wrote (past the L1),
 //            normalises + splits them in its operand path ONCE (it computes all DH output channels of its rows: no per-N-tile
 //            prologue), LayerNorm 2' lane-locally again, and writes act(LN2'(h1')) in X16 split form for the next launch's conv.
 // A stack of n blocks is n + 1 launches (C | A B C | ... | A B) instead of 3 n + 1, h2 / S / the second copies never exist, and the
-// weights cross L2 -> LDS once per 256 rows instead of once per 128.  One workgroup (4 waves, one per SIMD, up to 512 registers) per CU.
+// weights cross L2 -> LDS once per 128 rows for ALL DH output channels (gemm_x3_k: once per 128 rows and 128 channels).  One workgroup (4 waves, one
+// per SIMD, 440-470 registers) per CU.
+// STATUS (round 6, NOTES.md E, profiles/r06): correct on every width, trace and test -- and NOT faster than the launches it replaces (a dual block
+// 1 058-1 114 us against 920-960 us): with one wave per SIMD nobody covers that wave's DMA issue, fragment latency, vector-ALU phases and barriers
+// (everything that is not an MFMA takes 773 us of the launch by itself), and 582 one-per-CU workgroups are three rounds for 2.27 rounds of work.
+// Option bn_chain (HD_OPT_BN_CHAIN) therefore defaults to 0; the kernel stays as a tested alternative and as the record of the experiment.
 // Arithmetic: the same three-term split products with fp32 accumulation, k tiles in the same order as gemm_x3_k (taps outer); phase A's
 // accumulators are bit-identical to the tap GEMM's, LayerNorm statistics and phase B's in-step k order differ in the last ulp.
 #pragma once
